@@ -1,0 +1,240 @@
+"""GPU parity: HIP surfel rasteriser (through the C ABI) against the CPU oracle.
+
+Integer / index outputs (radii, tile rectangles, tile counts, sort keys, sorted
+splat indices, tile ranges, contributor counts) must be bit-exact.  Floating
+outputs must agree within 1e-4 relative (BASELINE.json north_star); because
+alpha / transmittance thresholds are discontinuous, a vanishing fraction of
+pixels may flip a threshold under different exp() rounding, so the float
+comparison is (a) relative L2 error of each map <= 1e-4 and (b) at least
+99.95 % of elements within 1e-4*|ref| + 1e-4*mean|ref|.
+"""
+import numpy as np
+import pytest
+import torch
+
+from scenes import oracle_forward, scene
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def _settings(sc, dev, pixel_mask=None):
+    from vings_mono_amd.surfel import GaussianRasterizationSettings
+    return GaussianRasterizationSettings(
+        image_height=sc["H"], image_width=sc["W"], tanfovx=sc["tanfovx"], tanfovy=sc["tanfovy"],
+        bg=torch.from_numpy(sc["bg"]).to(dev), scale_modifier=1.0,
+        viewmatrix=torch.from_numpy(sc["view"].reshape(4, 4)).to(dev),
+        projmatrix=torch.from_numpy(sc["proj"].reshape(4, 4)).to(dev), sh_degree=0,
+        campos=torch.from_numpy(sc["campos"]).to(dev), prefiltered=False, debug=False,
+        pixel_mask=None if pixel_mask is None else torch.from_numpy(pixel_mask).to(dev),
+        u2_minus_u1=None if sc["flow"] is None else torch.from_numpy(sc["flow"]).to(dev))
+
+
+def _dev_inputs(sc, dev):
+    return {k: torch.from_numpy(sc[k]).to(dev) for k in
+            ("means3D", "colors", "opacities", "scales", "rotations")}
+
+
+def assert_close_maps(name, got, ref, rtol=RTOL, frac=0.9995, atol=0.0):
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, name
+    denom = np.sqrt((ref * ref).sum())
+    if denom == 0:
+        assert np.abs(got).max() == 0, name
+        return
+    rel_l2 = np.sqrt(((got - ref) ** 2).sum()) / denom
+    assert rel_l2 <= rtol, f"{name}: relative L2 {rel_l2:.3e}"
+    tol = rtol * np.abs(ref) + rtol * np.abs(ref).mean() + atol
+    ok = (np.abs(got - ref) <= tol).mean()
+    assert ok >= frac, f"{name}: only {ok:.6f} of elements within tolerance"
+
+
+def run_forward(sc, dev, pixel_mask=None):
+    from vings_mono_amd import surfel
+    inp = _dev_inputs(sc, dev)
+    st, aux = surfel.rasterize_forward(inp["means3D"], inp["colors"], inp["opacities"],
+                                       inp["scales"], inp["rotations"],
+                                       _settings(sc, dev, pixel_mask), keep_keys=True)
+    torch.cuda.synchronize()
+    return inp, st, aux
+
+
+CASES = [
+    dict(n=10000, W=640, H=480),                       # BASELINE config 1
+    dict(n=4000, W=250, H=131, with_flow=True, bg=(0.2, 0.5, 0.1)),  # ragged tiles
+    dict(n=20000, W=320, H=240, scale_mul=4.0),        # long tile lists, saturating pixels
+    dict(n=3000, W=200, H=120, scale_mul=0.05),        # sub-pixel splats: low-pass branch
+    dict(n=1, W=64, H=48),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_parity(case, oracle32, oracle64):
+    dev = torch.device("cuda:0")
+    sc = scene(**case)
+    ref = oracle_forward(oracle32, sc)
+    inp, st, _ = run_forward(sc, dev)
+    # ---- bit-exact integer work ----
+    np.testing.assert_array_equal(st.radii.cpu().numpy(), ref["radii"])
+    np.testing.assert_array_equal(st.tiles_touched.cpu().numpy().view(np.uint32)[:sc["means3D"].shape[0]],
+                                  ref["tiles_touched"])
+    np.testing.assert_array_equal(st.rect.cpu().numpy()[:sc["means3D"].shape[0]], ref["rect"])
+    assert st.D == ref["D"]
+    D = ref["D"]
+    np.testing.assert_array_equal(st.keys.cpu().numpy().view(np.uint64)[:D], ref["keys"])
+    np.testing.assert_array_equal(st.vals.cpu().numpy().view(np.uint32)[:D], ref["vals"])
+    np.testing.assert_array_equal(st.ranges.cpu().numpy().view(np.uint32), ref["ranges"])
+    vis = ref["radii"] > 0
+    np.testing.assert_array_equal(st.depth.cpu().numpy()[:vis.shape[0]][vis], ref["depth"][vis])
+    geom = st.geom.cpu().numpy()[:vis.shape[0]]
+    np.testing.assert_array_equal(geom[vis, 0:9], ref["transmat"][vis])
+    np.testing.assert_array_equal(geom[vis, 9:11], ref["xy"][vis])
+    np.testing.assert_array_equal(geom[vis, 11:15], ref["normal_opacity"][vis])
+    # ---- floating outputs ----
+    assert_close_maps("color", st.color.cpu().numpy(), ref["color"])
+    allmap = st.allmap.cpu().numpy()
+    for c, nm in enumerate(["depth", "alpha", "nx", "ny", "nz", "median", "dist", "flow_u", "flow_v"]):
+        if nm == "dist":
+            continue
+        assert_close_maps(nm, allmap[c], ref["allmap"][c])
+    # The distortion sum m^2*A + M2 - 2*m*M1 cancels O(1) float32 quantities down to ~1e-5, so
+    # two float32 evaluations in different order differ by far more than 1e-4 relative.  The
+    # statement checked instead: against the float64 oracle, the HIP kernel is as accurate as
+    # the float32 oracle (within 2x plus the float32 rounding floor).
+    ref64 = oracle_forward(oracle64, sc)["allmap"][6]
+    e_hip = np.sqrt(((allmap[6].astype(np.float64) - ref64) ** 2).sum())
+    e_f32 = np.sqrt(((ref["allmap"][6].astype(np.float64) - ref64) ** 2).sum())
+    assert e_hip <= 2.0 * e_f32 + 1e-6 * np.sqrt(ref64.size), (e_hip, e_f32)
+    assert_close_maps("final_T", st.final_T.cpu().numpy(), ref["final_T"])
+    nc = st.n_contrib.cpu().numpy().view(np.uint32)
+    assert (nc == ref["n_contrib"]).mean() >= 0.9995
+
+
+def test_forward_empty_and_culled(oracle32):
+    dev = torch.device("cuda:0")
+    sc = scene(64, 96, 64)
+    sc["means3D"][:, 2] = -5.0  # everything behind the camera
+    ref = oracle_forward(oracle32, sc)
+    assert ref["D"] == 0
+    inp, st, _ = run_forward(sc, dev)
+    assert st.D == 0
+    assert st.radii.abs().sum().item() == 0
+    np.testing.assert_array_equal(st.color.cpu().numpy(), ref["color"])
+    np.testing.assert_array_equal(st.allmap.cpu().numpy(), ref["allmap"])
+    np.testing.assert_array_equal(st.ranges.cpu().numpy(), 0)
+
+
+def test_pixel_mask_parity(oracle32):
+    dev = torch.device("cuda:0")
+    sc = scene(3000, 160, 96, bg=(0.1, 0.2, 0.3))
+    mask = np.random.default_rng(5).uniform(size=(96, 160)) > 0.3
+    ref = oracle_forward(oracle32, sc, pixel_mask=mask)
+    inp, st, _ = run_forward(sc, dev, pixel_mask=mask)
+    assert_close_maps("color", st.color.cpu().numpy(), ref["color"])
+    assert_close_maps("alpha", st.allmap.cpu().numpy()[1], ref["allmap"][1])
+    assert np.all(st.allmap.cpu().numpy()[:, ~mask] == 0)
+
+
+BWD_CASES = [
+    dict(n=10000, W=640, H=480),
+    dict(n=4000, W=250, H=131, with_flow=True, bg=(0.2, 0.5, 0.1)),
+    dict(n=6000, W=200, H=120, scale_mul=3.0),
+    dict(n=3000, W=200, H=120, scale_mul=0.05),
+]
+
+
+@pytest.mark.parametrize("case", BWD_CASES)
+def test_backward_parity(case, oracle32, oracle64):
+    from vings_mono_amd import surfel
+    dev = torch.device("cuda:0")
+    sc = scene(**case)
+    H, W = sc["H"], sc["W"]
+    rng = np.random.default_rng(11)
+    gC = rng.normal(size=(3, H, W)).astype(np.float32)
+    gA = (rng.normal(size=(9, H, W)) * 0.3).astype(np.float32)
+    ref_st = oracle_forward(oracle32, sc)
+    ref = oracle32.backward(ref_st, gC, gA)
+    inp, st, aux = run_forward(sc, dev)
+    out = surfel.rasterize_backward(st, aux, inp["means3D"], inp["scales"], inp["rotations"], 1.0,
+                                    torch.from_numpy(gC).to(dev), torch.from_numpy(gA).to(dev))
+    torch.cuda.synchronize()
+    d_means3D, d_means2D, d_colors, d_opac, d_scales, d_rot, d_scores = [o.cpu().numpy() for o in out]
+    # gradients are sums of many float32 terms in a different order: compare in relative L2
+    def rel(a, b):
+        return np.sqrt(((a.astype(np.float64) - b) ** 2).sum()) / max(np.sqrt((b.astype(np.float64) ** 2).sum()), 1e-30)
+    assert rel(d_colors, ref["colors"]) < RTOL
+    assert rel(d_opac.reshape(-1), ref["opacity"]) < RTOL
+    assert rel(d_scores, ref["scores"]) < RTOL
+    assert rel(d_means2D[:, :2], ref["xy"]) < RTOL
+    # dL/dT -> (means3D, scales, rotations) multiplies gradients by pixel-sized factors that
+    # cancel, so two float32 evaluations differ by ~1e-3 relative.  Checked instead: measured
+    # against the float64 oracle, the HIP result is as accurate as the float32 oracle.
+    ref64_st = oracle_forward(oracle64, sc)
+    ref64 = oracle64.backward(ref64_st, gC, gA)
+    for got, key in ((d_means3D, "means3D"), (d_scales, "scales"), (d_rot, "rots")):
+        e_hip, e_f32 = rel(got, ref64[key]), rel(ref[key], ref64[key])
+        assert e_hip <= max(2.0 * e_f32, RTOL), (key, e_hip, e_f32)
+        assert e_hip < 1e-2, (key, e_hip)
+    # splats the oracle never touched stay exactly zero
+    untouched = ref["scores"][:, 0] == 0
+    assert np.all(d_scores[untouched] == 0)
+    assert np.all(d_means3D[untouched] == 0)
+
+
+def test_autograd_module_api():
+    """The drop-in module surface: keyword call, no_grad, means2D=None, scores.grad under a
+    zero loss (/root/reference/scripts/loop/loop_model.py:185-186)."""
+    from vings_mono_amd.surfel import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    sc = scene(2000, 160, 96)
+    inp = _dev_inputs(sc, dev)
+    for k in inp:
+        inp[k].requires_grad_(True)
+    scores = torch.zeros((2000, 2), device=dev, requires_grad=True)
+    means2D = torch.zeros((2000, 3), device=dev, requires_grad=True)
+    rast = GaussianRasterizer(raster_settings=_settings(sc, dev))
+    rgb, radii, allmap = rast(means3D=inp["means3D"], means2D=means2D, shs=None,
+                              colors_precomp=inp["colors"], opacities=inp["opacities"],
+                              scales=inp["scales"], rotations=inp["rotations"], scores=scores,
+                              cov3D_precomp=None)
+    assert rgb.shape == (3, 96, 160) and allmap.shape[0] >= 9 and radii.shape == (2000,)
+    (rgb * 0).sum().backward()
+    assert scores.grad is not None and scores.grad[:, 0].sum().item() > 0
+    assert inp["means3D"].grad.abs().sum().item() == 0
+    with torch.no_grad():
+        rgb2, _, _ = rast(means3D=inp["means3D"], means2D=None, shs=None,
+                          colors_precomp=inp["colors"], opacities=inp["opacities"],
+                          scales=inp["scales"], rotations=inp["rotations"])
+    assert torch.equal(rgb2, rgb.detach())
+
+
+def test_sparse_adam_parity(oracle32):
+    from vings_mono_amd.surfel import SparseGaussianAdam
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(2)
+    N = 5000
+    widths = {"_xyz": 3, "_rgb": 3, "_opacity": 1, "_scaling": 2, "_rotation": 4}
+    lrs = {"_xyz": 1.6e-4, "_rgb": 2.5e-3, "_opacity": 5e-2, "_scaling": 5e-3, "_rotation": 1e-3}
+    params = {k: torch.nn.Parameter(torch.from_numpy(rng.normal(size=(N, m)).astype(np.float32)).to(dev))
+              for k, m in widths.items()}
+    opt = SparseGaussianAdam([{"params": [params[k]], "lr": lrs[k], "name": k} for k in widths],
+                             lr=0.0, eps=1e-15)
+    ref_p = {k: v.detach().cpu().numpy().copy() for k, v in params.items()}
+    ref_m = {k: np.zeros_like(v) for k, v in ref_p.items()}
+    ref_v = {k: np.zeros_like(v) for k, v in ref_p.items()}
+    for it in range(3):
+        vis = rng.uniform(size=N) > 0.35
+        for k in widths:
+            g = rng.normal(size=ref_p[k].shape).astype(np.float32)
+            params[k].grad = torch.from_numpy(g).to(dev)
+            oracle32.sparse_adam(ref_p[k], g, ref_m[k], ref_v[k], vis, lrs[k])
+        opt.step(torch.from_numpy(vis).to(dev), N)
+        opt.zero_grad()
+    torch.cuda.synchronize()
+    for k in widths:
+        # same float32 expression order, no contraction: bit-exact
+        np.testing.assert_array_equal(params[k].detach().cpu().numpy(), ref_p[k])
+        np.testing.assert_array_equal(opt.state[params[k]]["exp_avg"].cpu().numpy(), ref_m[k])
+        np.testing.assert_array_equal(opt.state[params[k]]["exp_avg_sq"].cpu().numpy(), ref_v[k])

@@ -1,0 +1,89 @@
+"""ctypes binding of libvings_hip.so (the C ABI declared in include/vings_hip.h).
+
+There is no CPU fallback: if the shared object is missing or a call fails the
+caller gets an exception.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvings_hip.so")
+
+_c = ctypes
+_P = _c.c_void_p
+
+_SIGNATURES = {
+    "vings_last_error": (_c.c_char_p, []),
+    "vings_abi_version": (_c.c_int, []),
+    "vings_surfel_project": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float] + [_P] * 14 +
+                             [_c.POINTER(_c.c_int64), _P]),
+    "vings_surfel_bin_workspace_bytes": (_c.c_size_t, [_c.c_int64]),
+    "vings_surfel_bin": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int64] + [_P] * 8 +
+                         [_c.c_size_t, _P]),
+    "vings_surfel_blend_forward": (_c.c_int, [_c.c_int, _c.c_int] + [_P] * 10),
+    "vings_surfel_blend_backward": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int] + [_P] * 11),
+    "vings_surfel_project_backward": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float] +
+                                      [_P] * 15),
+    "vings_sparse_adam": (_c.c_int, [_P] * 5 + [_c.c_float] * 4 + [_c.c_int, _c.c_int, _P]),
+    "vings_sparse_adam_multi": (_c.c_int, [_c.c_int] + [_P] * 7 + [_c.c_float] * 3 +
+                                [_c.c_int, _P]),
+}
+
+_lib = None
+
+
+class VingsError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VingsError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C vings_mono_amd/csrc` (hipcc, gfx950)")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name, None)
+            if fn is None:
+                continue  # optional groups are bound by their own modules
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def bind(name, restype, argtypes):
+    fn = getattr(lib(), name)
+    fn.restype = restype
+    fn.argtypes = argtypes
+    return fn
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().vings_last_error().decode("utf-8", "replace")
+        raise VingsError(f"{what} failed with status {rc}: {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL). The tensor must be contiguous."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "tensor handed to the C ABI must be contiguous"
+    return t.data_ptr()
+
+
+def stream_ptr(device=None):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu_tensor(t, name, dtype=None):
+    if not t.is_cuda:
+        raise VingsError(f"{name} must live on the GPU (got {t.device}); there is no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise VingsError(f"{name} must be {dtype} (got {t.dtype})")

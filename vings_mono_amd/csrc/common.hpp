@@ -1,0 +1,78 @@
+// Shared host/device helpers for libvings_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/vings_hip.h"
+
+namespace vings {
+
+void set_error(const char* fmt, ...);
+
+#define VINGS_CHECK_HIP(expr)                                                             \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            ::vings::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),     \
+                               __FILE__, __LINE__);                                       \
+            return VINGS_ERR_HIP;                                                         \
+        }                                                                                 \
+    } while (0)
+
+#define VINGS_REQUIRE(cond, msg)                                                          \
+    do {                                                                                  \
+        if (!(cond)) {                                                                    \
+            ::vings::set_error("argument check failed: %s (%s)", #cond, msg);             \
+            return VINGS_ERR_ARG;                                                         \
+        }                                                                                 \
+    } while (0)
+
+#define VINGS_LAUNCH_CHECK() VINGS_CHECK_HIP(hipGetLastError())
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- wave64 primitives -----------------------------------------------------
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
+// Sum over the 64 lanes of a wave; every lane receives the total.
+// xor-1 / xor-2 via quad_perm, then row_half_mirror / row_mirror inside the
+// 16-lane DPP row, then two cross-row exchanges.
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);  // row_half_mirror
+    v += dpp_f<0x140>(v);  // row_mirror
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Inclusive prefix sum over the wave.
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o, 64);
+        if (l >= o) v += t;
+    }
+    return v;
+}
+
+}  // namespace vings

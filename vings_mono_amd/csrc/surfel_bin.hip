@@ -1,0 +1,277 @@
+// Tile binning for the surfel rasteriser on gfx950: key emission
+// (tile << 32 | float bits of depth), a stable least-significant-digit radix
+// sort written for 64-lane wavefronts, and per-tile range extraction.
+//
+// The sort order is fully determined by (tile, depth bits, splat index):
+// each splat emits at most one instance per tile and instances are emitted
+// in splat order, so a stable sort on the key reproduces the CPU oracle's
+// order bit for bit.
+//
+// Serves the binning stage of GaussianRasterizer.forward
+// (/root/reference/scripts/gaussian/gaussian_base.py:193-203).
+#include "common.hpp"
+
+namespace vings {
+
+constexpr int kSortThreads = 256;
+constexpr int kSortItems = 8;                        // keys per lane per tile
+constexpr int kSortTile = kSortThreads * kSortItems;  // 2048 keys per workgroup
+constexpr int kRadixBits = 8;
+constexpr int kRadix = 1 << kRadixBits;
+constexpr int kMaxPasses = 8;
+
+// ---------------------------------------------------------------------------
+// duplicate with keys: lane i owns splat i; its output offset is the
+// exclusive prefix of tiles_touched, rebuilt here from the per-block prefix.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void emit_keys_kernel(
+    int N, int gx, const float* __restrict__ depth, const int32_t* __restrict__ rect,
+    const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_prefix,
+    uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    __shared__ uint32_t wtot[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t cnt = i < N ? tiles_touched[i] : 0u;
+    const uint32_t inc = wave_scan_incl(cnt);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    uint32_t off = block_prefix[blockIdx.x] + inc - cnt;
+    for (int k = 0; k < w; ++k) off += wtot[k];
+    if (cnt == 0) return;
+    const int4 r = reinterpret_cast<const int4*>(rect)[i];
+    const uint32_t dbits = __float_as_uint(depth[i]);
+    for (int y = r.y; y < r.w; ++y)
+        for (int x = r.x; x < r.z; ++x) {
+            const uint64_t key = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;
+            keys[off] = key;
+            vals[off] = (uint32_t)i;
+            ++off;
+        }
+}
+
+// ---------------------------------------------------------------------------
+// radix sort
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t digit_of(uint64_t k, int shift) {
+    return (uint32_t)(k >> shift) & (kRadix - 1);
+}
+
+// Global digit histograms of every pass in one read of the keys:
+// ghist[pass][256].
+__global__ __launch_bounds__(256) void sort_global_hist_kernel(
+    const uint64_t* __restrict__ keys, int64_t D, int passes, uint32_t* __restrict__ ghist) {
+    __shared__ uint32_t h[kMaxPasses * kRadix];
+    for (int k = threadIdx.x; k < passes * kRadix; k += 256) h[k] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < D; i += stride) {
+        const uint64_t k = keys[i];
+        for (int p = 0; p < passes; ++p) atomicAdd(&h[p * kRadix + digit_of(k, p * kRadixBits)], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < passes * kRadix; k += 256)
+        if (h[k]) atomicAdd(&ghist[k], h[k]);
+}
+
+// Per-tile digit histogram of one pass: thist[digit][tile].
+__global__ __launch_bounds__(kSortThreads) void sort_tile_hist_kernel(
+    const uint64_t* __restrict__ keys, int64_t D, int shift, int ntiles,
+    uint32_t* __restrict__ thist) {
+    __shared__ uint32_t h[kRadix];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const int64_t i = base + r * kSortThreads + threadIdx.x;
+        if (i < D) atomicAdd(&h[digit_of(keys[i], shift)], 1u);
+    }
+    __syncthreads();
+    thist[(size_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// One wave per digit: exclusive scan of that digit's row of thist, offset by
+// the number of keys with a smaller digit (from the global histogram).
+__global__ __launch_bounds__(64) void sort_scan_kernel(uint32_t* __restrict__ thist, int ntiles,
+                                                       const uint32_t* __restrict__ ghist_pass) {
+    const int digit = blockIdx.x;
+    const int lane = threadIdx.x;
+    uint32_t base = 0;
+    for (int k = lane; k < digit; k += 64) base += ghist_pass[k];
+    base = wave_sum_u32(base);
+    uint32_t* row = thist + (size_t)digit * ntiles;
+    uint32_t carry = base;
+    for (int t0 = 0; t0 < ntiles; t0 += 64) {
+        const int t = t0 + lane;
+        const uint32_t v = t < ntiles ? row[t] : 0u;
+        const uint32_t inc = wave_scan_incl(v);
+        if (t < ntiles) row[t] = carry + inc - v;
+        carry += __shfl(inc, 63, 64);
+    }
+}
+
+// Stable scatter of one tile.  Keys are held in a wave-striped arrangement
+// (item r of lane l of wave w sits at tile_base + w*512 + r*64 + l) so that
+// walking r = 0..7 visits each wave's segment in memory order.  Within a
+// round the rank of a key among equal digits is the number of lower lanes
+// holding the same digit, found with one ballot per digit bit.
+__global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(
+    const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t D, int shift,
+    int ntiles, const uint32_t* __restrict__ thist) {
+    __shared__ uint32_t wcount[4][kRadix];  // per-wave digit counts, then prefixes
+    __shared__ uint32_t gbase[kRadix];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int k = threadIdx.x; k < 4 * kRadix; k += kSortThreads) (&wcount[0][0])[k] = 0;
+    gbase[threadIdx.x] = thist[(size_t)threadIdx.x * ntiles + blockIdx.x];
+    __syncthreads();
+
+    const int64_t wbase = (int64_t)blockIdx.x * kSortTile + w * (kSortItems * 64);
+    uint64_t key[kSortItems];
+    uint32_t val[kSortItems];
+    uint32_t rank[kSortItems];
+    const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const int64_t i = wbase + r * 64 + lane;
+        const bool valid = i < D;
+        key[r] = valid ? keys_in[i] : ~0ull;
+        val[r] = valid ? vals_in[i] : 0u;
+        const uint32_t d = digit_of(key[r], shift);
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < kRadixBits; ++b) {
+            const uint64_t m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        // all lanes in `peers` share digit d (invalid lanes excluded)
+        const uint32_t before = wcount[w][d];  // read before the leader updates it
+        const uint32_t below = __popcll(peers & lt_mask);
+        rank[r] = before + below;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && below == 0) wcount[w][d] = before + __popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // exclusive prefix over the 4 waves for each digit
+    {
+        const int d = threadIdx.x;
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t c = wcount[k][d];
+            wcount[k][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const int64_t i = wbase + r * 64 + lane;
+        if (i < D) {
+            const uint32_t d = digit_of(key[r], shift);
+            const uint32_t dst = gbase[d] + wcount[w][d] + rank[r];
+            keys_out[dst] = key[r];
+            vals_out[dst] = val[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint64_t* __restrict__ keys,
+                                                          int64_t D, uint32_t* __restrict__ ranges) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= D) return;
+    const uint32_t t = (uint32_t)(keys[i] >> 32);
+    if (i == 0 || (uint32_t)(keys[i - 1] >> 32) != t) ranges[2 * t] = (uint32_t)i;
+    if (i == D - 1 || (uint32_t)(keys[i + 1] >> 32) != t) ranges[2 * t + 1] = (uint32_t)(i + 1);
+}
+
+static int sort_passes(int T) {
+    int bits = 0;
+    while ((1 << bits) < T) ++bits;
+    return (32 + bits + kRadixBits - 1) / kRadixBits;
+}
+
+struct BinWorkspace {
+    uint64_t* keys_alt;
+    uint32_t* vals_alt;
+    uint32_t* ghist;  // [kMaxPasses][256]
+    uint32_t* thist;  // [256][ntiles]
+    size_t bytes;
+};
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static BinWorkspace carve(void* ws, int64_t D) {
+    BinWorkspace b;
+    const int ntiles = cdiv(D > 0 ? D : 1, kSortTile);
+    size_t off = 0;
+    char* p = (char*)ws;
+    b.keys_alt = (uint64_t*)(p + off); off += align256(sizeof(uint64_t) * (size_t)(D > 0 ? D : 1));
+    b.vals_alt = (uint32_t*)(p + off); off += align256(sizeof(uint32_t) * (size_t)(D > 0 ? D : 1));
+    b.ghist = (uint32_t*)(p + off);    off += align256(sizeof(uint32_t) * kMaxPasses * kRadix);
+    b.thist = (uint32_t*)(p + off);    off += align256(sizeof(uint32_t) * kRadix * (size_t)ntiles);
+    b.bytes = off;
+    return b;
+}
+
+}  // namespace vings
+
+using namespace vings;
+
+extern "C" size_t vings_surfel_bin_workspace_bytes(int64_t D) { return carve(nullptr, D).bytes; }
+
+extern "C" int vings_surfel_bin(int N, int H, int W, int64_t D, const float* depth,
+                                const int32_t* rect, const uint32_t* tiles_touched,
+                                const uint32_t* block_prefix, uint64_t* keys_sorted,
+                                uint32_t* vals_sorted, uint32_t* ranges, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    VINGS_REQUIRE(N >= 0 && H > 0 && W > 0 && D >= 0, "sizes");
+    VINGS_REQUIRE(D < ((int64_t)1 << 32), "instance count must fit 32 bits");
+    VINGS_REQUIRE(ranges != nullptr, "ranges");
+    hipStream_t s = (hipStream_t)stream;
+    const int gx = (W + 15) / 16, gy = (H + 15) / 16;
+    const int T = gx * gy;
+    VINGS_CHECK_HIP(hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)T, s));
+    if (D == 0 || N == 0) return VINGS_OK;
+    VINGS_REQUIRE(depth && rect && tiles_touched && block_prefix && keys_sorted && vals_sorted &&
+                      workspace,
+                  "null pointer");
+    VINGS_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+    const BinWorkspace b = carve(workspace, D);
+    if (workspace_bytes < b.bytes) {
+        set_error("bin workspace too small: %zu < %zu", workspace_bytes, b.bytes);
+        return VINGS_ERR_CAPACITY;
+    }
+    const int passes = sort_passes(T);
+    // ping-pong so that the last pass lands in keys_sorted / vals_sorted
+    uint64_t* kbuf[2] = {keys_sorted, b.keys_alt};
+    uint32_t* vbuf[2] = {vals_sorted, b.vals_alt};
+    int cur = (passes % 2 == 0) ? 0 : 1;
+
+    emit_keys_kernel<<<cdiv(N, 256), 256, 0, s>>>(N, gx, depth, rect, tiles_touched, block_prefix,
+                                                  kbuf[cur], vbuf[cur]);
+    VINGS_LAUNCH_CHECK();
+
+    const int ntiles = cdiv(D, kSortTile);
+    VINGS_CHECK_HIP(hipMemsetAsync(b.ghist, 0, sizeof(uint32_t) * kMaxPasses * kRadix, s));
+    const int hist_blocks = ntiles < 2048 ? ntiles : 2048;
+    sort_global_hist_kernel<<<hist_blocks, 256, 0, s>>>(kbuf[cur], D, passes, b.ghist);
+    VINGS_LAUNCH_CHECK();
+    for (int p = 0; p < passes; ++p) {
+        const int shift = p * kRadixBits;
+        sort_tile_hist_kernel<<<ntiles, kSortThreads, 0, s>>>(kbuf[cur], D, shift, ntiles, b.thist);
+        VINGS_LAUNCH_CHECK();
+        sort_scan_kernel<<<kRadix, 64, 0, s>>>(b.thist, ntiles, b.ghist + p * kRadix);
+        VINGS_LAUNCH_CHECK();
+        sort_scatter_kernel<<<ntiles, kSortThreads, 0, s>>>(kbuf[cur], vbuf[cur], kbuf[cur ^ 1],
+                                                            vbuf[cur ^ 1], D, shift, ntiles,
+                                                            b.thist);
+        VINGS_LAUNCH_CHECK();
+        cur ^= 1;
+    }
+    // cur == 0 here by construction
+    tile_ranges_kernel<<<cdiv(D, 256), 256, 0, s>>>(keys_sorted, D, ranges);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}

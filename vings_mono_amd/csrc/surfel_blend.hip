@@ -1,0 +1,369 @@
+// Front-to-back alpha blending of sorted surfels and its backward pass, gfx950.
+//
+// One 256-lane workgroup (4 wave64) per 16x16 pixel tile, one lane per pixel;
+// each wave covers a 16x4 pixel strip.  The tile's sorted splat list is
+// streamed through LDS in batches of 256 packed 80-byte records
+// (one gather per lane, then every lane reads the same record: LDS
+// broadcast, no bank conflicts).
+//
+// Backward walks the same list back to front.  Per splat the 20 partial
+// gradients of the contributing pixels are summed across the wave, the four
+// waves combine in an LDS accumulator for the batch, and each batch is
+// flushed with one global float atomic per (splat, component).
+//
+// Serves GaussianRasterizer.forward / backward as called at
+// /root/reference/scripts/gaussian/gaussian_base.py:193-203,382 and consumed
+// at gaussian_base.py:205-219,387.
+#include "common.hpp"
+
+namespace vings {
+
+constexpr float kNearN = 0.2f;
+constexpr float kFarN = 100.0f;
+constexpr float kFilterInvSq = 2.0f;
+constexpr float kAlphaMax = 0.99f;
+constexpr float kAlphaMin = 1.0f / 255.0f;
+constexpr float kTMin = 0.0001f;
+constexpr int kBatch = 256;
+constexpr int kRec4 = VINGS_GEOM_STRIDE / 4;  // float4 per record
+
+struct Splat {  // unpacked view of one record
+    float Tu[3], Tv[3], Tw[3];
+    float cx, cy;
+    float n[3];
+    float opa;
+    float rgb[3];
+    float fl[2];
+};
+
+__device__ __forceinline__ Splat unpack(const float4* __restrict__ r) {
+    const float4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4];
+    Splat s;
+    s.Tu[0] = a.x; s.Tu[1] = a.y; s.Tu[2] = a.z;
+    s.Tv[0] = a.w; s.Tv[1] = b.x; s.Tv[2] = b.y;
+    s.Tw[0] = b.z; s.Tw[1] = b.w; s.Tw[2] = c.x;
+    s.cx = c.y; s.cy = c.z;
+    s.n[0] = c.w; s.n[1] = d.x; s.n[2] = d.y;
+    s.opa = d.z;
+    s.rgb[0] = d.w; s.rgb[1] = e.x; s.rgb[2] = e.y;
+    s.fl[0] = e.z; s.fl[1] = e.w;
+    return s;
+}
+
+struct Hit {
+    float kx, ky, kz, lx, ly, lz, pz, sx, sy, rho3d, rho2d, dx, dy, depth, G, alpha;
+};
+
+// Ray / splat intersection and opacity at pixel (fx, fy); false = no contribution.
+__device__ __forceinline__ bool eval_hit(const Splat& s, float fx, float fy, Hit& h) {
+    h.kx = fx * s.Tw[0] - s.Tu[0]; h.ky = fx * s.Tw[1] - s.Tu[1]; h.kz = fx * s.Tw[2] - s.Tu[2];
+    h.lx = fy * s.Tw[0] - s.Tv[0]; h.ly = fy * s.Tw[1] - s.Tv[1]; h.lz = fy * s.Tw[2] - s.Tv[2];
+    const float px = h.ky * h.lz - h.kz * h.ly;
+    const float py = h.kz * h.lx - h.kx * h.lz;
+    h.pz = h.kx * h.ly - h.ky * h.lx;
+    if (h.pz == 0.f) return false;
+    const float rz = 1.0f / h.pz;
+    h.sx = px * rz; h.sy = py * rz;
+    h.rho3d = h.sx * h.sx + h.sy * h.sy;
+    h.dx = s.cx - fx; h.dy = s.cy - fy;
+    h.rho2d = kFilterInvSq * (h.dx * h.dx + h.dy * h.dy);
+    const float rho = fminf(h.rho3d, h.rho2d);
+    h.depth = (h.rho3d <= h.rho2d) ? (h.sx * s.Tw[0] + h.sy * s.Tw[1]) + s.Tw[2] : s.Tw[2];
+    if (h.depth < kNearN) return false;
+    const float power = -0.5f * rho;
+    if (power > 0.f) return false;
+    h.G = __expf(power);
+    h.alpha = fminf(kAlphaMax, s.opa * h.G);
+    return h.alpha >= kAlphaMin;
+}
+
+__device__ __forceinline__ void stage_batch(float4* __restrict__ lds, const float* __restrict__ geom,
+                                            const uint32_t* __restrict__ vals, uint32_t idx,
+                                            uint32_t end, uint32_t* __restrict__ ids) {
+    if (idx < end) {
+        const uint32_t id = vals[idx];
+        if (ids) ids[threadIdx.x] = id;
+        const float4* src = reinterpret_cast<const float4*>(geom + (size_t)id * VINGS_GEOM_STRIDE);
+#pragma unroll
+        for (int k = 0; k < kRec4; ++k) lds[threadIdx.x * kRec4 + k] = src[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void blend_fwd_kernel(
+    int H, int W, int gx, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ vals,
+    const float* __restrict__ geom, const float* __restrict__ bg,
+    const uint8_t* __restrict__ pixel_mask, float* __restrict__ out_color,
+    float* __restrict__ allmap, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
+    __shared__ float4 rec[kBatch * kRec4];
+    const int tile = blockIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const int px = tx * 16 + (threadIdx.x & 15), py = ty * 16 + (threadIdx.x >> 4);
+    const bool inside = px < W && py < H;
+    const size_t HW = (size_t)H * W;
+    const size_t pix = (size_t)py * W + px;
+    const bool masked = inside && pixel_mask && pixel_mask[pix] == 0;
+    bool done = !inside || masked;
+    const float fx = (float)px, fy = (float)py;
+    const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+
+    float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, F0 = 0, F1 = 0;
+    float T = 1.f, Dd = 0, M1 = 0, M2 = 0, dist = 0, med = 0;
+    uint32_t contributor = 0, last = 0, medc = 0;
+    const float c1 = kFarN / (kFarN - kNearN);
+
+    for (uint32_t base = r0; base < r1; base += kBatch) {
+        if (__syncthreads_and(done)) break;
+        stage_batch(rec, geom, vals, base + threadIdx.x, r1, nullptr);
+        __syncthreads();
+        const int cnt = min((uint32_t)kBatch, r1 - base);
+        for (int j = 0; j < cnt && !done; ++j) {
+            ++contributor;
+            const Splat s = unpack(rec + j * kRec4);
+            Hit h;
+            if (!eval_hit(s, fx, fy, h)) continue;
+            const float test_T = T * (1.f - h.alpha);
+            if (test_T < kTMin) { done = true; continue; }
+            const float w = h.alpha * T;
+            const float A = 1.f - T;
+            const float m = c1 * (1.f - kNearN / h.depth);
+            dist += (m * m * A + M2 - 2.f * m * M1) * w;
+            Dd += h.depth * w;
+            M1 += m * w;
+            M2 += m * m * w;
+            if (T > 0.5f) { med = h.depth; medc = contributor; }
+            N0 += s.n[0] * w; N1 += s.n[1] * w; N2 += s.n[2] * w;
+            C0 += s.rgb[0] * w; C1 += s.rgb[1] * w; C2 += s.rgb[2] * w;
+            F0 += s.fl[0] * w; F1 += s.fl[1] * w;
+            T = test_T;
+            last = contributor;
+        }
+    }
+    if (!inside) return;
+    final_T[pix] = T; final_T[HW + pix] = M1; final_T[2 * HW + pix] = M2;
+    n_contrib[pix] = last; n_contrib[HW + pix] = medc;
+    if (masked) {
+        out_color[pix] = bg[0]; out_color[HW + pix] = bg[1]; out_color[2 * HW + pix] = bg[2];
+#pragma unroll
+        for (int c = 0; c < VINGS_AUX_CHANNELS; ++c) allmap[c * HW + pix] = 0.f;
+        return;
+    }
+    out_color[pix] = C0 + T * bg[0];
+    out_color[HW + pix] = C1 + T * bg[1];
+    out_color[2 * HW + pix] = C2 + T * bg[2];
+    allmap[0 * HW + pix] = Dd;
+    allmap[1 * HW + pix] = 1.f - T;
+    allmap[2 * HW + pix] = N0;
+    allmap[3 * HW + pix] = N1;
+    allmap[4 * HW + pix] = N2;
+    allmap[5 * HW + pix] = med;
+    allmap[6 * HW + pix] = dist;
+    allmap[7 * HW + pix] = F0;
+    allmap[8 * HW + pix] = F1;
+}
+
+// ---------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------
+constexpr int kGrad = VINGS_GEOM_STRIDE;  // 20 gradient components per splat
+
+__global__ __launch_bounds__(256) void blend_bwd_kernel(
+    int H, int W, int gx, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ vals,
+    const float* __restrict__ geom, const float* __restrict__ bg,
+    const uint8_t* __restrict__ pixel_mask, const float* __restrict__ final_T,
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
+    const float* __restrict__ dL_dallmap, float* __restrict__ dgeom) {
+    __shared__ float4 rec[kBatch * kRec4];
+    __shared__ float acc[kBatch * kGrad];
+    __shared__ uint32_t ids[kBatch];
+    __shared__ uint32_t wmax[4];
+    const int tile = blockIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const int px = tx * 16 + (threadIdx.x & 15), py = ty * 16 + (threadIdx.x >> 4);
+    const bool inside = px < W && py < H;
+    const size_t HW = (size_t)H * W;
+    const size_t pix = (size_t)py * W + px;
+    const bool active = inside && !(pixel_mask && pixel_mask[pix] == 0);
+    const float fx = (float)px, fy = (float)py;
+    const uint32_t r0 = ranges[2 * tile];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+
+    const uint32_t last = active ? n_contrib[pix] : 0u;
+    const uint32_t medc = active ? n_contrib[HW + pix] : 0u;
+    // the deepest contributor over the tile bounds the walk
+    uint32_t mx = last;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, o, 64));
+    if (lane == 0) wmax[wv] = mx;
+    __syncthreads();
+    const uint32_t maxlast = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    if (maxlast == 0) return;
+
+    float T_final = 1.f, M1f = 0.f, M2f = 0.f;
+    float gC0 = 0, gC1 = 0, gC2 = 0, gD = 0, gA = 0, gN0 = 0, gN1 = 0, gN2 = 0, gMed = 0, gDist = 0,
+          gF0 = 0, gF1 = 0;
+    if (last > 0) {
+        T_final = final_T[pix]; M1f = final_T[HW + pix]; M2f = final_T[2 * HW + pix];
+        gC0 = dL_dcolor[pix]; gC1 = dL_dcolor[HW + pix]; gC2 = dL_dcolor[2 * HW + pix];
+        gD = dL_dallmap[pix];
+        gA = dL_dallmap[HW + pix];
+        gN0 = dL_dallmap[2 * HW + pix]; gN1 = dL_dallmap[3 * HW + pix]; gN2 = dL_dallmap[4 * HW + pix];
+        gMed = dL_dallmap[5 * HW + pix];
+        gDist = dL_dallmap[6 * HW + pix];
+        gF0 = dL_dallmap[7 * HW + pix]; gF1 = dL_dallmap[8 * HW + pix];
+    }
+    const float A_final = 1.f - T_final;
+    const float bg_dot = bg[0] * gC0 + bg[1] * gC1 + bg[2] * gC2;
+    const float gabs = fabsf(gC0) + fabsf(gC1) + fabsf(gC2);
+    const float c1 = kFarN / (kFarN - kNearN);
+    const float c2 = (kFarN * kNearN) / (kFarN - kNearN);
+
+    float T = T_final, last_alpha = 0.f;
+    float accC0 = 0, accC1 = 0, accC2 = 0, lastC0 = 0, lastC1 = 0, lastC2 = 0;
+    float accN0 = 0, accN1 = 0, accN2 = 0, lastN0 = 0, lastN1 = 0, lastN2 = 0;
+    float accF0 = 0, accF1 = 0, lastF0 = 0, lastF1 = 0;
+    float accD = 0, lastD = 0, accA = 0, accW = 0, lastW = 0;
+
+    const int nbatch = (int)((maxlast + kBatch - 1) / kBatch);
+    for (int b = nbatch - 1; b >= 0; --b) {
+        const uint32_t bstart = (uint32_t)b * kBatch;
+        const int cnt = (int)min((uint32_t)kBatch, maxlast - bstart);
+        __syncthreads();  // previous batch fully flushed
+        stage_batch(rec, geom, vals, r0 + bstart + threadIdx.x, r0 + bstart + cnt, ids);
+        for (int k = threadIdx.x; k < cnt * kGrad; k += 256) acc[k] = 0.f;
+        __syncthreads();
+        for (int j = cnt - 1; j >= 0; --j) {
+            const uint32_t pos = bstart + j;
+            float g[kGrad];
+#pragma unroll
+            for (int k = 0; k < kGrad; ++k) g[k] = 0.f;
+            bool contrib = false;
+            if (pos < last) {
+                const Splat s = unpack(rec + j * kRec4);
+                Hit h;
+                if (eval_hit(s, fx, fy, h)) {
+                    contrib = true;
+                    const float alpha = h.alpha;
+                    const float one_m = 1.f - alpha;
+                    T = T / one_m;
+                    const float w = alpha * T;
+                    float dL_dalpha = 0.f;
+                    accC0 = last_alpha * lastC0 + (1.f - last_alpha) * accC0; lastC0 = s.rgb[0];
+                    accC1 = last_alpha * lastC1 + (1.f - last_alpha) * accC1; lastC1 = s.rgb[1];
+                    accC2 = last_alpha * lastC2 + (1.f - last_alpha) * accC2; lastC2 = s.rgb[2];
+                    dL_dalpha += (s.rgb[0] - accC0) * gC0 + (s.rgb[1] - accC1) * gC1 +
+                                 (s.rgb[2] - accC2) * gC2;
+                    g[15] = w * gC0; g[16] = w * gC1; g[17] = w * gC2;
+                    accF0 = last_alpha * lastF0 + (1.f - last_alpha) * accF0; lastF0 = s.fl[0];
+                    accF1 = last_alpha * lastF1 + (1.f - last_alpha) * accF1; lastF1 = s.fl[1];
+                    dL_dalpha += (s.fl[0] - accF0) * gF0 + (s.fl[1] - accF1) * gF1;
+                    // distortion
+                    float dL_dz = 0.f;
+                    const float rd = 1.0f / h.depth;
+                    const float m = c1 * (1.f - kNearN * rd);
+                    const float dm_dd = c2 * rd * rd;
+                    if (pos + 1 == medc) dL_dz += gMed;
+                    const float Wd = (M2f + m * m * A_final - 2.f * m * M1f) * gDist;
+                    accW = last_alpha * lastW + (1.f - last_alpha) * accW; lastW = Wd;
+                    dL_dalpha += Wd - accW;
+                    dL_dz += 2.f * w * (m * A_final - M1f) * gDist * dm_dd;
+                    // alpha channel
+                    accA = last_alpha + (1.f - last_alpha) * accA;
+                    dL_dalpha += (1.f - accA) * gA;
+                    // depth channel
+                    accD = last_alpha * lastD + (1.f - last_alpha) * accD; lastD = h.depth;
+                    dL_dalpha += (h.depth - accD) * gD;
+                    // normal channels
+                    accN0 = last_alpha * lastN0 + (1.f - last_alpha) * accN0; lastN0 = s.n[0];
+                    accN1 = last_alpha * lastN1 + (1.f - last_alpha) * accN1; lastN1 = s.n[1];
+                    accN2 = last_alpha * lastN2 + (1.f - last_alpha) * accN2; lastN2 = s.n[2];
+                    dL_dalpha += (s.n[0] - accN0) * gN0 + (s.n[1] - accN1) * gN1 +
+                                 (s.n[2] - accN2) * gN2;
+                    g[11] = w * gN0; g[12] = w * gN1; g[13] = w * gN2;
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-T_final / one_m) * bg_dot;
+                    g[18] = w;
+                    g[19] = w * gabs;
+                    const float dL_dG = s.opa * dL_dalpha;
+                    g[14] = h.G * dL_dalpha;
+                    dL_dz += w * gD;
+                    if (h.rho3d <= h.rho2d) {
+                        const float dsx = dL_dG * -h.G * h.sx + dL_dz * s.Tw[0];
+                        const float dsy = dL_dG * -h.G * h.sy + dL_dz * s.Tw[1];
+                        const float rz = 1.0f / h.pz;
+                        const float dpx = dsx * rz, dpy = dsy * rz;
+                        const float dpz = -(dpx * h.sx + dpy * h.sy);
+                        const float dkx = h.ly * dpz - h.lz * dpy;
+                        const float dky = h.lz * dpx - h.lx * dpz;
+                        const float dkz = h.lx * dpy - h.ly * dpx;
+                        const float dlx = dpy * h.kz - dpz * h.ky;
+                        const float dly = dpz * h.kx - dpx * h.kz;
+                        const float dlz = dpx * h.ky - dpy * h.kx;
+                        g[0] = -dkx; g[1] = -dky; g[2] = -dkz;
+                        g[3] = -dlx; g[4] = -dly; g[5] = -dlz;
+                        g[6] = fx * dkx + fy * dlx + dL_dz * h.sx;
+                        g[7] = fx * dky + fy * dly + dL_dz * h.sy;
+                        g[8] = fx * dkz + fy * dlz + dL_dz;
+                    } else {
+                        g[9] = dL_dG * (-h.G * kFilterInvSq * h.dx);
+                        g[10] = dL_dG * (-h.G * kFilterInvSq * h.dy);
+                        g[8] = dL_dz;
+                    }
+                }
+            }
+            if (__ballot(contrib) == 0ull) continue;  // wave-uniform
+#pragma unroll
+            for (int k = 0; k < kGrad; ++k) {
+                const float v = wave_sum(g[k]);
+                if (lane == 0) atomicAdd(&acc[j * kGrad + k], v);
+            }
+        }
+        __syncthreads();
+        // flush: consecutive lanes write consecutive floats of the accumulator
+        for (int k = threadIdx.x; k < cnt * kGrad; k += 256) {
+            const float v = acc[k];
+            if (v != 0.f) {
+                const int j = k / kGrad, c = k - j * kGrad;
+                atomicAdd(&dgeom[(size_t)ids[j] * kGrad + c], v);
+            }
+        }
+    }
+}
+
+}  // namespace vings
+
+using namespace vings;
+
+extern "C" int vings_surfel_blend_forward(int H, int W, const uint32_t* ranges,
+                                          const uint32_t* vals_sorted, const float* geom,
+                                          const float* bg, const uint8_t* pixel_mask,
+                                          float* out_color, float* allmap, float* final_T,
+                                          uint32_t* n_contrib, void* stream) {
+    VINGS_REQUIRE(H > 0 && W > 0, "sizes");
+    VINGS_REQUIRE(ranges && bg && out_color && allmap && final_T && n_contrib, "null pointer");
+    VINGS_REQUIRE(((uintptr_t)geom & 15) == 0, "geom must be 16-byte aligned");
+    const int gx = (W + 15) / 16, gy = (H + 15) / 16;
+    blend_fwd_kernel<<<gx * gy, 256, 0, (hipStream_t)stream>>>(
+        H, W, gx, ranges, vals_sorted, geom, bg, pixel_mask, out_color, allmap, final_T, n_contrib);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}
+
+extern "C" int vings_surfel_blend_backward(int N, int H, int W, const uint32_t* ranges,
+                                           const uint32_t* vals_sorted, const float* geom,
+                                           const float* bg, const uint8_t* pixel_mask,
+                                           const float* final_T, const uint32_t* n_contrib,
+                                           const float* dL_dcolor, const float* dL_dallmap,
+                                           float* dgeom, void* stream) {
+    VINGS_REQUIRE(N >= 0 && H > 0 && W > 0, "sizes");
+    if (N == 0) return VINGS_OK;
+    VINGS_REQUIRE(ranges && bg && final_T && n_contrib && dL_dcolor && dL_dallmap && dgeom,
+                  "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    VINGS_CHECK_HIP(hipMemsetAsync(dgeom, 0, sizeof(float) * (size_t)N * VINGS_GEOM_STRIDE, s));
+    const int gx = (W + 15) / 16, gy = (H + 15) / 16;
+    blend_bwd_kernel<<<gx * gy, 256, 0, s>>>(H, W, gx, ranges, vals_sorted, geom, bg, pixel_mask,
+                                             final_T, n_contrib, dL_dcolor, dL_dallmap, dgeom);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}

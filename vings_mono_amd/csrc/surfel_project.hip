@@ -1,0 +1,334 @@
+// Surfel projection ("preprocess") forward and backward for gfx950.
+//
+// One lane per splat.  This translation unit is compiled with
+// -ffp-contract=off: the tile rectangle, radius and depth key of every splat
+// must round exactly like the float32 CPU oracle so that tile/sort indices
+// are bit-exact; the arithmetic below is therefore written as plain
+// left-to-right float expressions and must not be re-associated.
+//
+// Serves GaussianRasterizer.forward/backward as called at
+// /root/reference/scripts/gaussian/gaussian_base.py:193-203,382.
+#include "common.hpp"
+
+namespace vings {
+
+constexpr float kNear = 0.2f;
+constexpr float kFilterSize = 0.707106f;
+
+struct PixProj {  // B = ndc2pix * (P * w2c), rows x,y,w
+    float b[3][4];
+};
+
+__device__ __forceinline__ PixProj pixel_projection(const float* __restrict__ proj, int W, int H) {
+    PixProj B;
+    const float hw = (float)W / 2, hh = (float)H / 2;
+    const float ow = (float)(W - 1) / 2, oh = (float)(H - 1) / 2;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float p0 = proj[c * 4 + 0], p1 = proj[c * 4 + 1], p3 = proj[c * 4 + 3];
+        B.b[0][c] = hw * p0 + ow * p3;
+        B.b[1][c] = hh * p1 + oh * p3;
+        B.b[2][c] = p3;
+    }
+    return B;
+}
+
+__device__ __forceinline__ void quat_to_R(const float4 q, float R[3][3]) {
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    R[0][0] = 1 - 2 * (y * y + z * z);
+    R[0][1] = 2 * (x * y - r * z);
+    R[0][2] = 2 * (x * z + r * y);
+    R[1][0] = 2 * (x * y + r * z);
+    R[1][1] = 1 - 2 * (x * x + z * z);
+    R[1][2] = 2 * (y * z - r * x);
+    R[2][0] = 2 * (x * z - r * y);
+    R[2][1] = 2 * (y * z + r * x);
+    R[2][2] = 1 - 2 * (x * x + y * y);
+}
+
+struct SplatFrame {
+    float A[3][3];  // rows Tu, Tv, Tw
+    float R[3][3];
+    float n[3];     // view-space normal, camera facing
+    float pv[3];
+    float sx, sy, mult;
+};
+
+__device__ __forceinline__ void splat_frame(const float* __restrict__ means3D,
+                                            const float* __restrict__ scales,
+                                            const float* __restrict__ rots,
+                                            const float* __restrict__ view, const PixProj& B,
+                                            float scale_mod, int i, SplatFrame& f) {
+    const float p0 = means3D[3 * i], p1 = means3D[3 * i + 1], p2 = means3D[3 * i + 2];
+    f.pv[0] = view[0] * p0 + view[4] * p1 + view[8] * p2 + view[12];
+    f.pv[1] = view[1] * p0 + view[5] * p1 + view[9] * p2 + view[13];
+    f.pv[2] = view[2] * p0 + view[6] * p1 + view[10] * p2 + view[14];
+    const float4 q = reinterpret_cast<const float4*>(rots)[i];
+    quat_to_R(q, f.R);
+    const float2 s = reinterpret_cast<const float2*>(scales)[i];
+    f.sx = scale_mod * s.x;
+    f.sy = scale_mod * s.y;
+    const float L0[3] = {f.R[0][0] * f.sx, f.R[1][0] * f.sx, f.R[2][0] * f.sx};
+    const float L1[3] = {f.R[0][1] * f.sy, f.R[1][1] * f.sy, f.R[2][1] * f.sy};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        f.A[r][0] = B.b[r][0] * L0[0] + B.b[r][1] * L0[1] + B.b[r][2] * L0[2];
+        f.A[r][1] = B.b[r][0] * L1[0] + B.b[r][1] * L1[1] + B.b[r][2] * L1[2];
+        f.A[r][2] = B.b[r][0] * p0 + B.b[r][1] * p1 + B.b[r][2] * p2 + B.b[r][3];
+    }
+    const float nw[3] = {f.R[0][2], f.R[1][2], f.R[2][2]};
+    f.n[0] = view[0] * nw[0] + view[4] * nw[1] + view[8] * nw[2];
+    f.n[1] = view[1] * nw[0] + view[5] * nw[1] + view[9] * nw[2];
+    f.n[2] = view[2] * nw[0] + view[6] * nw[1] + view[10] * nw[2];
+    const float cosv = -(f.pv[0] * f.n[0] + f.pv[1] * f.n[1] + f.pv[2] * f.n[2]);
+    f.mult = cosv == 0.f ? 0.f : (cosv > 0.f ? 1.f : -1.f);
+}
+
+__global__ __launch_bounds__(256) void project_fwd_kernel(
+    int N, int H, int W, float scale_mod, const float* __restrict__ means3D,
+    const float* __restrict__ scales, const float* __restrict__ rots,
+    const float* __restrict__ opac, const float* __restrict__ colors,
+    const float* __restrict__ flow, const float* __restrict__ view,
+    const float* __restrict__ proj, float* __restrict__ geom, float* __restrict__ depth,
+    int32_t* __restrict__ radii, int32_t* __restrict__ rect, uint32_t* __restrict__ tiles_touched,
+    uint32_t* __restrict__ block_counts) {
+    __shared__ uint32_t wsum[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t touched = 0;
+    if (i < N) {
+        const int gx = (W + 15) / 16, gy = (H + 15) / 16;
+        int32_t rad = 0;
+        int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+        float dep = 0.f;
+        const PixProj B = pixel_projection(proj, W, H);
+        SplatFrame f;
+        splat_frame(means3D, scales, rots, view, B, scale_mod, i, f);
+        bool ok = f.pv[2] > kNear && f.mult != 0.f;
+        float cx = 0.f, cy = 0.f;
+        if (ok) {
+            const float* Tu = f.A[0];
+            const float* Tv = f.A[1];
+            const float* Tw = f.A[2];
+            const float t0 = 9.f, t1 = 9.f, t2 = -1.f;
+            const float d = t0 * Tw[0] * Tw[0] + t1 * Tw[1] * Tw[1] + t2 * Tw[2] * Tw[2];
+            ok = d != 0.f;
+            if (ok) {
+                const float inv = 1.f / d;
+                const float f0 = inv * t0, f1 = inv * t1, f2 = inv * t2;
+                cx = f0 * Tu[0] * Tw[0] + f1 * Tu[1] * Tw[1] + f2 * Tu[2] * Tw[2];
+                cy = f0 * Tv[0] * Tw[0] + f1 * Tv[1] * Tw[1] + f2 * Tv[2] * Tw[2];
+                const float ex =
+                    cx * cx - (f0 * Tu[0] * Tu[0] + f1 * Tu[1] * Tu[1] + f2 * Tu[2] * Tu[2]);
+                const float ey =
+                    cy * cy - (f0 * Tv[0] * Tv[0] + f1 * Tv[1] * Tv[1] + f2 * Tv[2] * Tv[2]);
+                const float hx = sqrtf(fmaxf(1e-4f, ex)), hy = sqrtf(fmaxf(1e-4f, ey));
+                const float radius = ceilf(fmaxf(fmaxf(hx, hy), 3.f * kFilterSize));
+                ok = (radius < 1e7f) && (cx == cx) && (cy == cy) && (cx > -1e9f && cx < 1e9f) &&
+                     (cy > -1e9f && cy < 1e9f);
+                if (ok) {
+                    x0 = min(gx, max(0, (int)((cx - radius) / 16)));
+                    y0 = min(gy, max(0, (int)((cy - radius) / 16)));
+                    x1 = min(gx, max(0, (int)((cx + radius + 15) / 16)));
+                    y1 = min(gy, max(0, (int)((cy + radius + 15) / 16)));
+                    touched = (uint32_t)((x1 - x0) * (y1 - y0));
+                    ok = touched != 0;
+                    if (ok) {
+                        rad = (int32_t)radius;
+                        dep = f.pv[2];
+                    }
+                }
+            }
+        }
+        if (!ok) { touched = 0; x0 = y0 = x1 = y1 = 0; }
+        radii[i] = rad;
+        depth[i] = dep;
+        tiles_touched[i] = touched;
+        reinterpret_cast<int4*>(rect)[i] = make_int4(x0, y0, x1, y1);
+        if (ok) {
+            float4* g = reinterpret_cast<float4*>(geom + (size_t)i * VINGS_GEOM_STRIDE);
+            const float o = opac[i];
+            const float c0 = colors[3 * i], c1 = colors[3 * i + 1], c2 = colors[3 * i + 2];
+            float fl0 = 0.f, fl1 = 0.f;
+            if (flow) { fl0 = flow[2 * i]; fl1 = flow[2 * i + 1]; }
+            g[0] = make_float4(f.A[0][0], f.A[0][1], f.A[0][2], f.A[1][0]);
+            g[1] = make_float4(f.A[1][1], f.A[1][2], f.A[2][0], f.A[2][1]);
+            g[2] = make_float4(f.A[2][2], cx, cy, f.mult * f.n[0]);
+            g[3] = make_float4(f.mult * f.n[1], f.mult * f.n[2], o, c0);
+            g[4] = make_float4(c1, c2, fl0, fl1);
+        }
+    }
+    // per-block instance count (feeds the exclusive scan over blocks)
+    uint32_t s = wave_sum_u32(touched);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// Single workgroup: in-place exclusive scan of block_counts[0..nb), total in [nb].
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(uint32_t* __restrict__ counts, int nb) {
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < nb ? counts[i] : 0u;
+        const uint32_t inc = wave_scan_incl(v);
+        if (lane == 63) wtot[w] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int k = 0; k < w; ++k) woff += wtot[k];
+        const uint32_t carry = carry_s;
+        if (i < nb) counts[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[nb] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void project_bwd_kernel(
+    int N, int H, int W, float scale_mod, const float* __restrict__ means3D,
+    const float* __restrict__ scales, const float* __restrict__ rots,
+    const float* __restrict__ view, const float* __restrict__ proj,
+    const int32_t* __restrict__ radii, const float* __restrict__ dgeom,
+    float* __restrict__ d_means3D, float* __restrict__ d_scales, float* __restrict__ d_rots,
+    float* __restrict__ d_opac, float* __restrict__ d_colors, float* __restrict__ d_means2D,
+    float* __restrict__ scores) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float dm[3] = {0, 0, 0}, ds[2] = {0, 0}, dq[4] = {0, 0, 0, 0};
+    float dop = 0, dc[3] = {0, 0, 0}, dxy[2] = {0, 0}, sc[2] = {0, 0};
+    if (radii[i] > 0) {
+        const float4* g4 = reinterpret_cast<const float4*>(dgeom + (size_t)i * VINGS_GEOM_STRIDE);
+        const float4 g0 = g4[0], g1 = g4[1], g2 = g4[2], g3 = g4[3], g4v = g4[4];
+        float dA[3][3] = {{g0.x, g0.y, g0.z}, {g0.w, g1.x, g1.y}, {g1.z, g1.w, g2.x}};
+        dxy[0] = g2.y; dxy[1] = g2.z;
+        const float dnv[3] = {g2.w, g3.x, g3.y};
+        dop = g3.z;
+        dc[0] = g3.w; dc[1] = g4v.x; dc[2] = g4v.y;
+        sc[0] = g4v.z; sc[1] = g4v.w;
+
+        const PixProj B = pixel_projection(proj, W, H);
+        SplatFrame f;
+        splat_frame(means3D, scales, rots, view, B, scale_mod, i, f);
+        if (dxy[0] != 0.f || dxy[1] != 0.f) {
+            const float* Tu = f.A[0];
+            const float* Tv = f.A[1];
+            const float* Tw = f.A[2];
+            const float t[3] = {9.f, 9.f, -1.f};
+            const float d = t[0] * Tw[0] * Tw[0] + t[1] * Tw[1] * Tw[1] + t[2] * Tw[2] * Tw[2];
+            const float inv = 1.f / d;
+            const float ff[3] = {inv * t[0], inv * t[1], inv * t[2]};
+            const float cx = ff[0] * Tu[0] * Tw[0] + ff[1] * Tu[1] * Tw[1] + ff[2] * Tu[2] * Tw[2];
+            const float cy = ff[0] * Tv[0] * Tw[0] + ff[1] * Tv[1] * Tw[1] + ff[2] * Tv[2] * Tw[2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                dA[0][k] += dxy[0] * ff[k] * Tw[k];
+                dA[1][k] += dxy[1] * ff[k] * Tw[k];
+                dA[2][k] += dxy[0] * (ff[k] * Tu[k] - 2 * cx * ff[k] * Tw[k]) +
+                            dxy[1] * (ff[k] * Tv[k] - 2 * cy * ff[k] * Tw[k]);
+            }
+        }
+        float dL0[3], dL1[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            dL0[k] = B.b[0][k] * dA[0][0] + B.b[1][k] * dA[1][0] + B.b[2][k] * dA[2][0];
+            dL1[k] = B.b[0][k] * dA[0][1] + B.b[1][k] * dA[1][1] + B.b[2][k] * dA[2][1];
+            dm[k] = B.b[0][k] * dA[0][2] + B.b[1][k] * dA[1][2] + B.b[2][k] * dA[2][2];
+        }
+        const float dn[3] = {f.mult * dnv[0], f.mult * dnv[1], f.mult * dnv[2]};
+        float dnw[3];
+        dnw[0] = view[0] * dn[0] + view[1] * dn[1] + view[2] * dn[2];
+        dnw[1] = view[4] * dn[0] + view[5] * dn[1] + view[6] * dn[2];
+        dnw[2] = view[8] * dn[0] + view[9] * dn[1] + view[10] * dn[2];
+        float g[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            g[k][0] = f.sx * dL0[k];
+            g[k][1] = f.sy * dL1[k];
+            g[k][2] = dnw[k];
+        }
+        ds[0] = scale_mod * (f.R[0][0] * dL0[0] + f.R[1][0] * dL0[1] + f.R[2][0] * dL0[2]);
+        ds[1] = scale_mod * (f.R[0][1] * dL1[0] + f.R[1][1] * dL1[1] + f.R[2][1] * dL1[2]);
+        const float4 q = reinterpret_cast<const float4*>(rots)[i];
+        const float r = q.x, x = q.y, y = q.z, z = q.w;
+        dq[0] = 2 * (-z * g[0][1] + y * g[0][2] + z * g[1][0] - x * g[1][2] - y * g[2][0] + x * g[2][1]);
+        dq[1] = 2 * (y * g[0][1] + z * g[0][2] + y * g[1][0] - 2 * x * g[1][1] - r * g[1][2] +
+                     z * g[2][0] + r * g[2][1] - 2 * x * g[2][2]);
+        dq[2] = 2 * (-2 * y * g[0][0] + x * g[0][1] + r * g[0][2] + x * g[1][0] + z * g[1][2] -
+                     r * g[2][0] + z * g[2][1] - 2 * y * g[2][2]);
+        dq[3] = 2 * (-2 * z * g[0][0] - r * g[0][1] + x * g[0][2] + r * g[1][0] - 2 * z * g[1][1] +
+                     y * g[1][2] + x * g[2][0] + y * g[2][1]);
+    }
+    d_means3D[3 * i] = dm[0]; d_means3D[3 * i + 1] = dm[1]; d_means3D[3 * i + 2] = dm[2];
+    reinterpret_cast<float2*>(d_scales)[i] = make_float2(ds[0], ds[1]);
+    reinterpret_cast<float4*>(d_rots)[i] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+    d_opac[i] = dop;
+    d_colors[3 * i] = dc[0]; d_colors[3 * i + 1] = dc[1]; d_colors[3 * i + 2] = dc[2];
+    if (d_means2D) {
+        d_means2D[3 * i] = dxy[0]; d_means2D[3 * i + 1] = dxy[1]; d_means2D[3 * i + 2] = 0.f;
+    }
+    if (scores) reinterpret_cast<float2*>(scores)[i] = make_float2(sc[0], sc[1]);
+}
+
+}  // namespace vings
+
+using namespace vings;
+
+extern "C" int vings_surfel_project(int N, int H, int W, float scale_modifier,
+                                    const float* means3D, const float* scales,
+                                    const float* rotations, const float* opacities,
+                                    const float* colors, const float* flow,
+                                    const float* viewmatrix, const float* projmatrix,
+                                    float* geom, float* depth, int32_t* radii, int32_t* rect,
+                                    uint32_t* tiles_touched, uint32_t* block_prefix,
+                                    int64_t* num_instances_host, void* stream) {
+    VINGS_REQUIRE(N >= 0 && H > 0 && W > 0, "sizes");
+    VINGS_REQUIRE(num_instances_host != nullptr, "num_instances_host");
+    *num_instances_host = 0;
+    if (N == 0) return VINGS_OK;
+    VINGS_REQUIRE(means3D && scales && rotations && opacities && colors && viewmatrix &&
+                      projmatrix && geom && depth && radii && rect && tiles_touched && block_prefix,
+                  "null pointer");
+    VINGS_REQUIRE((((uintptr_t)geom | (uintptr_t)rotations | (uintptr_t)rect) & 15) == 0,
+                  "geom/rotations/rect must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = cdiv(N, 256);
+    project_fwd_kernel<<<nb, 256, 0, s>>>(N, H, W, scale_modifier, means3D, scales, rotations,
+                                          opacities, colors, flow, viewmatrix, projmatrix, geom,
+                                          depth, radii, rect, tiles_touched, block_prefix);
+    VINGS_LAUNCH_CHECK();
+    scan_blocks_kernel<<<1, 1024, 0, s>>>(block_prefix, nb);
+    VINGS_LAUNCH_CHECK();
+    uint32_t total = 0;
+    VINGS_CHECK_HIP(hipMemcpyAsync(&total, block_prefix + nb, sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, s));
+    VINGS_CHECK_HIP(hipStreamSynchronize(s));
+    *num_instances_host = (int64_t)total;
+    return VINGS_OK;
+}
+
+extern "C" int vings_surfel_project_backward(int N, int H, int W, float scale_modifier,
+                                             const float* means3D, const float* scales,
+                                             const float* rotations, const float* viewmatrix,
+                                             const float* projmatrix, const int32_t* radii,
+                                             const float* dgeom, float* dL_dmeans3D,
+                                             float* dL_dscales, float* dL_drotations,
+                                             float* dL_dopacities, float* dL_dcolors,
+                                             float* dL_dmeans2D, float* scores_grad,
+                                             void* stream) {
+    VINGS_REQUIRE(N >= 0 && H > 0 && W > 0, "sizes");
+    if (N == 0) return VINGS_OK;
+    VINGS_REQUIRE(means3D && scales && rotations && viewmatrix && projmatrix && radii && dgeom &&
+                      dL_dmeans3D && dL_dscales && dL_drotations && dL_dopacities && dL_dcolors,
+                  "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    project_bwd_kernel<<<cdiv(N, 256), 256, 0, s>>>(
+        N, H, W, scale_modifier, means3D, scales, rotations, viewmatrix, projmatrix, radii, dgeom,
+        dL_dmeans3D, dL_dscales, dL_drotations, dL_dopacities, dL_dcolors, dL_dmeans2D,
+        scores_grad);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}

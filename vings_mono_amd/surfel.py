@@ -1,0 +1,253 @@
+"""Host-side mirror of the reference's ``diff_surfel_rasterization`` extension.
+
+Same names, argument meaning and error behaviour as the module the reference
+imports at /root/reference/scripts/gaussian/gaussian_base.py:5-6:
+``GaussianRasterizationSettings``, ``GaussianRasterizer`` and
+``SparseGaussianAdam``.  All compute happens in libvings_hip.so through the C
+ABI of include/vings_hip.h; torch only provides device memory, the current
+stream and the autograd hook.
+"""
+import ctypes
+from typing import NamedTuple, Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+GEOM_STRIDE = 20
+AUX_CHANNELS = 9
+TILE = 16
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    """Fields as constructed at gaussian_base.py:160-177 (pixel_mask optional,
+    sky_utils.py:135-149; u2_minus_u1 optional, gaussian_model.py:268-286)."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+    pixel_mask: Optional[torch.Tensor] = None
+    u2_minus_u1: Optional[torch.Tensor] = None
+
+
+def _f32c(t, name):
+    _lib.require_gpu_tensor(t, name)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class SurfelForwardState:
+    """Device buffers produced by one forward pass (kept for backward / tests)."""
+    __slots__ = ("N", "H", "W", "D", "geom", "depth", "radii", "rect", "tiles_touched",
+                 "block_prefix", "keys", "vals", "ranges", "final_T", "n_contrib", "color",
+                 "allmap")
+
+
+def rasterize_forward(means3D, colors, opacities, scales, rotations, settings, keep_keys=False):
+    """Run projection -> binning -> blend. Returns a SurfelForwardState."""
+    L = _lib.lib()
+    dev = means3D.device
+    N = means3D.shape[0]
+    H, W = int(settings.image_height), int(settings.image_width)
+    st = SurfelForwardState()
+    st.N, st.H, st.W = N, H, W
+    view = _f32c(settings.viewmatrix, "viewmatrix")
+    proj = _f32c(settings.projmatrix, "projmatrix")
+    bg = _f32c(settings.bg, "bg")
+    flow = settings.u2_minus_u1
+    if flow is not None:
+        flow = _f32c(flow, "u2_minus_u1")
+        if flow.shape[0] != N:
+            raise _lib.VingsError("u2_minus_u1 must be [N,2]")
+    mask = settings.pixel_mask
+    if mask is not None:
+        _lib.require_gpu_tensor(mask, "pixel_mask")
+        if mask.numel() != H * W:
+            raise _lib.VingsError("pixel_mask must hold H*W entries")
+        mask = mask.reshape(-1).to(torch.uint8).contiguous()
+    stream = stream_ptr(dev)
+    nb = (N + 255) // 256
+    st.geom = torch.empty((max(N, 1), GEOM_STRIDE), dtype=torch.float32, device=dev)
+    st.depth = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
+    st.radii = torch.zeros(N, dtype=torch.int32, device=dev)
+    st.rect = torch.empty((max(N, 1), 4), dtype=torch.int32, device=dev)
+    st.tiles_touched = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+    st.block_prefix = torch.empty(nb + 1, dtype=torch.int32, device=dev)
+    d_host = ctypes.c_int64(0)
+    check(L.vings_surfel_project(
+        N, H, W, float(settings.scale_modifier), ptr(means3D), ptr(scales), ptr(rotations),
+        ptr(opacities), ptr(colors), ptr(flow), ptr(view), ptr(proj), ptr(st.geom), ptr(st.depth),
+        ptr(st.radii), ptr(st.rect), ptr(st.tiles_touched), ptr(st.block_prefix),
+        ctypes.byref(d_host), stream), "vings_surfel_project")
+    D = int(d_host.value)
+    st.D = D
+    T = ((W + TILE - 1) // TILE) * ((H + TILE - 1) // TILE)
+    st.keys = torch.empty(max(D, 1), dtype=torch.int64, device=dev)
+    st.vals = torch.empty(max(D, 1), dtype=torch.int32, device=dev)
+    st.ranges = torch.empty((T, 2), dtype=torch.int32, device=dev)
+    ws_bytes = int(L.vings_surfel_bin_workspace_bytes(D))
+    ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
+    ws_ptr = (ws.data_ptr() + 255) & ~255
+    check(L.vings_surfel_bin(N, H, W, D, ptr(st.depth), ptr(st.rect), ptr(st.tiles_touched),
+                             ptr(st.block_prefix), ptr(st.keys), ptr(st.vals), ptr(st.ranges),
+                             ws_ptr, ws_bytes, stream), "vings_surfel_bin")
+    st.color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    st.allmap = torch.empty((AUX_CHANNELS, H, W), dtype=torch.float32, device=dev)
+    st.final_T = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    st.n_contrib = torch.empty((2, H, W), dtype=torch.int32, device=dev)
+    check(L.vings_surfel_blend_forward(H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg),
+                                       ptr(mask), ptr(st.color), ptr(st.allmap), ptr(st.final_T),
+                                       ptr(st.n_contrib), stream), "vings_surfel_blend_forward")
+    if not keep_keys:
+        st.keys = None
+    return st, (view, proj, bg, mask, flow)
+
+
+def rasterize_backward(st, aux, means3D, scales, rotations, scale_modifier, g_color, g_allmap,
+                       want_means2D=True, want_scores=True):
+    L = _lib.lib()
+    dev = means3D.device
+    view, proj, bg, mask, _ = aux
+    N, H, W = st.N, st.H, st.W
+    stream = stream_ptr(dev)
+    dgeom = torch.empty((max(N, 1), GEOM_STRIDE), dtype=torch.float32, device=dev)
+    check(L.vings_surfel_blend_backward(
+        N, H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg), ptr(mask), ptr(st.final_T),
+        ptr(st.n_contrib), ptr(g_color), ptr(g_allmap), ptr(dgeom), stream),
+        "vings_surfel_blend_backward")
+    d_means3D = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    d_scales = torch.empty((N, 2), dtype=torch.float32, device=dev)
+    d_rot = torch.empty((N, 4), dtype=torch.float32, device=dev)
+    d_opac = torch.empty((N, 1), dtype=torch.float32, device=dev)
+    d_colors = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    d_means2D = torch.empty((N, 3), dtype=torch.float32, device=dev) if want_means2D else None
+    d_scores = torch.empty((N, 2), dtype=torch.float32, device=dev) if want_scores else None
+    check(L.vings_surfel_project_backward(
+        N, H, W, float(scale_modifier), ptr(means3D), ptr(scales), ptr(rotations), ptr(view),
+        ptr(proj), ptr(st.radii), ptr(dgeom), ptr(d_means3D), ptr(d_scales), ptr(d_rot),
+        ptr(d_opac), ptr(d_colors), ptr(d_means2D), ptr(d_scores), stream),
+        "vings_surfel_project_backward")
+    return d_means3D, d_means2D, d_colors, d_opac, d_scales, d_rot, d_scores
+
+
+class _RasterizeSurfels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, colors, opacities, scales, rotations, scores, settings):
+        means3D = _f32c(means3D, "means3D")
+        colors = _f32c(colors, "colors_precomp")
+        opacities = _f32c(opacities, "opacities")
+        scales = _f32c(scales, "scales")
+        rotations = _f32c(rotations, "rotations")
+        N = means3D.shape[0]
+        if colors.shape != (N, 3) or scales.shape != (N, 2) or rotations.shape != (N, 4) \
+                or opacities.numel() != N:
+            raise _lib.VingsError(
+                "expected means3D[N,3] colors[N,3] opacities[N,1] scales[N,2] rotations[N,4]")
+        st, aux = rasterize_forward(means3D, colors, opacities, scales, rotations, settings)
+        ctx.st, ctx.aux = st, aux
+        ctx.scale_modifier = float(settings.scale_modifier)
+        ctx.has_means2D = means2D is not None
+        ctx.has_scores = scores is not None
+        ctx.save_for_backward(means3D, scales, rotations)
+        radii = st.radii
+        ctx.mark_non_differentiable(radii)
+        return st.color, radii, st.allmap
+
+    @staticmethod
+    def backward(ctx, g_color, g_radii, g_allmap):
+        means3D, scales, rotations = ctx.saved_tensors
+        st = ctx.st
+        dev = means3D.device
+        if g_color is None:
+            g_color = torch.zeros((3, st.H, st.W), dtype=torch.float32, device=dev)
+        if g_allmap is None:
+            g_allmap = torch.zeros((AUX_CHANNELS, st.H, st.W), dtype=torch.float32, device=dev)
+        g_color = g_color.float().contiguous()
+        g_allmap = g_allmap.float().contiguous()
+        d_means3D, d_means2D, d_colors, d_opac, d_scales, d_rot, d_scores = rasterize_backward(
+            st, ctx.aux, means3D, scales, rotations, ctx.scale_modifier, g_color, g_allmap,
+            want_means2D=ctx.has_means2D, want_scores=ctx.has_scores)
+        return d_means3D, d_means2D, d_colors, d_opac, d_scales, d_rot, d_scores, None
+
+
+class GaussianRasterizer(torch.nn.Module):
+    """Callable with the keyword signature used at gaussian_base.py:193-203."""
+
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D=None, shs=None, colors_precomp=None, opacities=None,
+                scales=None, rotations=None, scores=None, cov3D_precomp=None):
+        if shs is not None or colors_precomp is None:
+            raise _lib.VingsError("only colors_precomp is supported (sh_degree 0, shs=None)")
+        if cov3D_precomp is not None:
+            raise _lib.VingsError("cov3D_precomp is not supported; pass scales and rotations")
+        if scales is None or rotations is None or opacities is None:
+            raise _lib.VingsError("scales, rotations and opacities are required")
+        return _RasterizeSurfels.apply(means3D, means2D, colors_precomp, opacities, scales,
+                                       rotations, scores, self.raster_settings)
+
+
+class SparseGaussianAdam(torch.optim.Adam):
+    """Adam that only touches rows flagged visible (no bias correction).
+
+    Constructed as ``SparseGaussianAdam(param_groups, lr=0.0, eps=1e-15)`` and
+    stepped as ``step(radii > 0, N)`` (gaussian_base.py:62,402).  State keys
+    ``exp_avg`` / ``exp_avg_sq`` match torch.optim.Adam because the reference
+    edits them by name when splats are added or pruned (gaussian_base.py:80-110).
+    """
+
+    def __init__(self, params, lr, eps):
+        super().__init__(params=params, lr=lr, eps=eps)
+
+    @torch.no_grad()
+    def step(self, visibility, N):
+        L = _lib.lib()
+        _lib.require_gpu_tensor(visibility, "visibility")
+        vis = visibility.reshape(-1).to(torch.uint8).contiguous()
+        if vis.numel() != N:
+            raise _lib.VingsError("visibility must hold N entries")
+        by_eps = {}
+        for group in self.param_groups:
+            if len(group["params"]) != 1:
+                raise _lib.VingsError("more than one tensor in group")
+            p = group["params"][0]
+            if p.grad is None:
+                continue
+            _lib.require_gpu_tensor(p, "param", torch.float32)
+            state = self.state[p]
+            if len(state) == 0:
+                state["step"] = torch.tensor(0.0, dtype=torch.float32)
+                state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if p.numel() % N != 0:
+                raise _lib.VingsError("parameter size is not a multiple of N")
+            b1, b2 = group.get("betas", (0.9, 0.999))
+            key = (float(group["eps"]), float(b1), float(b2))
+            by_eps.setdefault(key, []).append(
+                (p, p.grad.contiguous(), state["exp_avg"], state["exp_avg_sq"],
+                 p.numel() // N, float(group["lr"])))
+        stream = stream_ptr(vis.device)
+        for (eps, b1, b2), items in by_eps.items():
+            for c0 in range(0, len(items), 8):
+                chunk = items[c0:c0 + 8]
+                n = len(chunk)
+                PP = (ctypes.c_void_p * n)(*[ptr(c[0]) for c in chunk])
+                GG = (ctypes.c_void_p * n)(*[ptr(c[1]) for c in chunk])
+                MM = (ctypes.c_void_p * n)(*[ptr(c[2]) for c in chunk])
+                VV = (ctypes.c_void_p * n)(*[ptr(c[3]) for c in chunk])
+                WW = (ctypes.c_int * n)(*[c[4] for c in chunk])
+                LR = (ctypes.c_float * n)(*[c[5] for c in chunk])
+                check(L.vings_sparse_adam_multi(n, PP, GG, MM, VV, WW, LR, ptr(vis), b1, b2, eps,
+                                                N, stream), "vings_sparse_adam_multi")

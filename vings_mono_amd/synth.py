@@ -1,0 +1,163 @@
+"""Seeded synthetic inputs for the mapping hot path: pinhole cameras, splat
+clouds and dense-BA graphs.  Everything is generated on the CPU with a seeded
+``torch.Generator`` so every device and every rank sees identical bits.
+
+Camera conventions restate /root/reference/scripts/gaussian/cameras.py:7-67
+(``viewmatrix = w2c.T``, ``projmatrix = viewmatrix @ P.T``, znear 0.01,
+zfar 100, principal point ignored by the rasteriser path).
+"""
+import math
+
+import numpy as np
+import torch
+
+SEED_BASE = 20250124
+ZNEAR, ZFAR = 0.01, 100.0
+
+
+def focal_to_fov(focal, pixels):
+    return 2.0 * math.atan(pixels / (2.0 * focal))
+
+
+def projection_matrix(fov_x, fov_y, znear=ZNEAR, zfar=ZFAR):
+    """4x4 perspective matrix, column-vector convention, w_clip = z_view."""
+    tx, ty = math.tan(fov_x / 2.0), math.tan(fov_y / 2.0)
+    top, right = ty * znear, tx * znear
+    bottom, left = -top, -right
+    P = torch.zeros(4, 4, dtype=torch.float32)
+    P[0, 0] = 2.0 * znear / (right - left)
+    P[1, 1] = 2.0 * znear / (top - bottom)
+    P[0, 2] = (right + left) / (right - left)
+    P[1, 2] = (top + bottom) / (top - bottom)
+    P[2, 2] = zfar / (zfar - znear)
+    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    P[3, 2] = 1.0
+    return P
+
+
+class Camera:
+    """Matrices in the layout the rasteriser settings expect."""
+
+    def __init__(self, w2c, intrinsic):
+        # intrinsic: dict fu,fv,cu,cv,H,W with fu/cu vertical, fv/cv horizontal
+        # (/root/reference/scripts/gaussian/tf.py:27-45).
+        self.width, self.height = int(intrinsic["W"]), int(intrinsic["H"])
+        fov_y = focal_to_fov(intrinsic["fu"], self.height)
+        fov_x = focal_to_fov(intrinsic["fv"], self.width)
+        self.world_view_transform = w2c.T.contiguous()
+        self.projection_matrix = projection_matrix(fov_x, fov_y).T.contiguous().to(w2c.device)
+        self.full_proj_transform = (self.world_view_transform @ self.projection_matrix).contiguous()
+        self.camera_center = torch.linalg.inv(self.world_view_transform)[3, :3].contiguous()
+        self.tanfovx = math.tan(fov_x * 0.5)
+        self.tanfovy = math.tan(fov_y * 0.5)
+
+
+def intrinsic_for(W, H):
+    f = 0.6 * W
+    return {"fu": f, "fv": f, "cu": (H - 1) / 2.0, "cv": (W - 1) / 2.0, "H": H, "W": W}
+
+
+def window_poses(n_views, x_extent=None):
+    """c2w [n,4,4]: view k at x = 0.4 k metres, yaw 1 degree * k, looking down +z."""
+    out = torch.zeros(n_views, 4, 4, dtype=torch.float32)
+    for k in range(n_views):
+        a = math.radians(1.0 * k)
+        c, s = math.cos(a), math.sin(a)
+        R = torch.tensor([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]], dtype=torch.float32)
+        out[k, :3, :3] = R
+        out[k, 0, 3] = 0.4 * k
+        out[k, 3, 3] = 1.0
+    return out
+
+
+def make_splats(n, W, H, n_views=1, seed=SEED_BASE, z_range=(1.5, 60.0)):
+    """Raw (pre-activation) splat parameters filling the union frustum of a window."""
+    g = torch.Generator().manual_seed(seed)
+    intr = intrinsic_for(W, H)
+    fx = intr["fv"]
+    c2w = window_poses(n_views)
+    u = (torch.rand(n, generator=g) * 1.1 - 0.05) * W
+    v = (torch.rand(n, generator=g) * 1.1 - 0.05) * H
+    lz0, lz1 = math.log(z_range[0]), math.log(z_range[1])
+    z = torch.exp(torch.rand(n, generator=g) * (lz1 - lz0) + lz0)
+    k = torch.randint(0, n_views, (n,), generator=g)
+    xc = torch.stack([(u - (W - 1) / 2.0) / fx * z, (v - (H - 1) / 2.0) / fx * z, z], 1)
+    Rk, tk = c2w[k, :3, :3], c2w[k, :3, 3]
+    xyz = torch.einsum("nij,nj->ni", Rk, xc) + tk
+    r_px = torch.exp(torch.randn(n, 2, generator=g) * 0.6 + math.log(2.5))
+    scaling = torch.log(z[:, None] * r_px / fx)
+    rotation = torch.randn(n, 4, generator=g)
+    opacity = torch.randn(n, 1, generator=g) * 1.5
+    rgb = torch.rand(n, 3, generator=g)
+    return {"_xyz": xyz.contiguous(), "_rgb": rgb.contiguous(), "_opacity": opacity.contiguous(),
+            "_scaling": scaling.contiguous(), "_rotation": rotation.contiguous()}
+
+
+def perturb_splats(params, seed=SEED_BASE + 1):
+    """Copy used to render ground-truth images: xyz += N(0,0.01), rgb += N(0,0.05)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {k: v.clone() for k, v in params.items()}
+    out["_xyz"] += torch.randn(out["_xyz"].shape, generator=g) * 0.01
+    out["_rgb"] = (out["_rgb"] + torch.randn(out["_rgb"].shape, generator=g) * 0.05).clamp(0, 1)
+    return out
+
+
+def activate(params):
+    """Activations of /root/reference/scripts/gaussian/gaussian_base.py:44-48,64-72."""
+    return dict(
+        means3D=params["_xyz"],
+        colors=params["_rgb"],
+        opacities=torch.sigmoid(params["_opacity"]),
+        scales=torch.exp(params["_scaling"]),
+        rotations=torch.nn.functional.normalize(params["_rotation"]),
+    )
+
+
+# ---------------------------------------------------------------------------
+# dense bundle adjustment graphs
+# ---------------------------------------------------------------------------
+def quat_from_yaw(a):
+    # rotation about +y by angle a, (x,y,z,w)
+    return np.array([0.0, math.sin(a / 2), 0.0, math.cos(a / 2)])
+
+
+def make_dba_problem(n_frames=9, ht=43, wd=77, n_edges=48, seed=SEED_BASE + 7, buffer=None,
+                     noise_px=0.5):
+    """Poses (world->cam, tx ty tz qx qy qz qw), inverse depths, edges, flow targets.
+
+    Frame 0 is the gauge frame (t0 = 1).  Edges are all ordered pairs with
+    1 <= |i-j| <= 3, padded with the longest-baseline pairs up to n_edges.
+    Targets are the exact reprojections plus N(0, noise_px) pixels.
+    """
+    from . import se3np
+    g = np.random.default_rng(seed)
+    B = buffer or n_frames
+    poses = np.zeros((B, 7), np.float64)
+    poses[:, 6] = 1.0
+    for k in range(n_frames):
+        a = math.radians(1.0 * k)
+        q = quat_from_yaw(a)          # c2w rotation
+        t = np.array([0.4 * k, 0.0, 0.0])
+        # world->cam = inverse of (R,t)
+        qi = q * np.array([-1, -1, -1, 1.0])
+        ti = -se3np.quat_rotate(qi, t)
+        poses[k, :3], poses[k, 3:] = ti, qi
+    disps = np.zeros((B, ht, wd), np.float64)
+    disps[:n_frames] = g.uniform(0.02, 0.8, size=(n_frames, ht, wd))
+    fx = 0.6 * (wd * 8) / 8.0
+    intr = np.array([fx, fx, (wd - 1) / 2.0, (ht - 1) / 2.0])
+    pairs = [(i, j) for i in range(n_frames) for j in range(n_frames) if 1 <= abs(i - j) <= 3]
+    extra = sorted([(i, j) for i in range(n_frames) for j in range(n_frames) if abs(i - j) > 3],
+                   key=lambda p: (-abs(p[0] - p[1]), p))
+    pairs = (pairs + extra)[:n_edges]
+    ii = np.array([p[0] for p in pairs], np.int64)
+    jj = np.array([p[1] for p in pairs], np.int64)
+    coords, _ = se3np.reproject(poses, disps, intr, ii, jj)
+    target = coords + g.normal(0, noise_px, size=coords.shape)       # [E,ht,wd,2]
+    weight = g.uniform(0, 1, size=coords.shape)
+    kx = np.unique(np.concatenate([np.arange(1, n_frames), ii]))
+    eta = 1e-3 * g.uniform(0.5, 1.5, size=(kx.shape[0], ht, wd))
+    return dict(poses=poses, disps=disps, intr=intr, disps_sens=np.zeros_like(disps),
+                target=np.ascontiguousarray(target.transpose(0, 3, 1, 2)),
+                weight=np.ascontiguousarray(weight.transpose(0, 3, 1, 2)),
+                eta=eta, ii=ii, jj=jj, t0=1, t1=n_frames)
