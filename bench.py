@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Mapping throughput benchmark for the MI355X hot path.
+
+Metric (BASELINE.json): mapping frames/sec (render + backward + BA) at 1.0 M
+splats, 1920x1080.  One *step* is one pass over an 8-keyframe window on every
+GPU: per view  render -> mapping loss -> rasteriser backward -> score
+bookkeeping -> (N>1: RCCL all-reduce of the packed splat gradients) -> sparse
+Adam, plus one dense bundle-adjustment call ``ba(itrs=2)`` per window.
+``value`` = views processed by all ranks / wall time of the timed steps.
+
+    python bench.py --gpus N --steps K --warmup W
+
+For N>1 the driver launches this file under torch.distributed.run, one rank
+per GPU.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--splats", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--views", type=int, default=8, help="keyframes per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dba", action="store_true")
+    ap.add_argument("--dba-grid", type=str, default="135x240")
+    return ap.parse_args()
+
+
+def algorithmic_bytes_blend_bwd(D, P, n_vis, C=9):
+    # per launch of the blend-backward kernel: staged records 64 B per instance,
+    # upstream gradients 4(3+C) B and saved forward state 4(C+3) B per pixel,
+    # packed gradient rows 84 B per visible splat
+    return 64 * D + 4 * (3 + C) * P + 4 * (C + 3) * P + 84 * n_vis
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (MI355X); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1 and args.gpus == 1, \
+        f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    from vings_mono_amd import harness, synth, parallel, profiling
+    W, H, V = args.width, args.height, args.views
+    intr = synth.intrinsic_for(W, H)
+    n_views_total = V * world
+    # identical splat replica on every rank; each rank owns V views of the window
+    raw = synth.make_splats(args.splats, W, H, n_views=n_views_total, seed=synth.SEED_BASE)
+    mapper = harness.SurfelMapper(raw, dev)
+    gt_mapper_params = {k: v.to(dev) for k, v in synth.perturb_splats(raw).items()}
+    c2w_all = synth.window_poses(n_views_total).to(dev)
+    my_views = list(range(rank * V, (rank + 1) * V))
+    gts = []
+    with torch.no_grad():
+        for k in my_views:
+            pred = harness.render(gt_mapper_params, torch.linalg.inv(c2w_all[k]), intr)
+            depth = pred["depth"].clone()
+            gts.append({"rgb": pred["rgb"].clone(), "depth": depth,
+                        "depth_cov": torch.ones_like(depth)})
+    del gt_mapper_params
+    reducer = parallel.GradReducer(mapper.n, dev, world)
+
+    dba = None
+    if not args.no_dba:
+        from vings_mono_amd import dba as dba_mod
+        ht, wd = (int(x) for x in args.dba_grid.split("x"))
+        dba = dba_mod.make_bench_problem(dev, ht, wd)
+
+    def step():
+        for i, k in enumerate(my_views):
+            w2c = torch.linalg.inv(c2w_all[k])
+            radii, cur = mapper.backward_view(w2c, intr, gts[i])
+            mapper.finish_view(radii, cur, k, reducer)
+        if dba is not None:
+            dba.run()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    profiling.enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = profiling.read()
+    profiling.enable(False)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    frames = n_views_total * args.steps
+    value = frames / elapsed
+
+    # ---- roofline of the dominant kernel (blend backward), measured with HIP events ----
+    stats = mapper.last_stats()
+    roof = None
+    if "blend_bwd" in prof and prof["blend_bwd"]["count"] > 0:
+        avg_ms = prof["blend_bwd"]["ms"] / prof["blend_bwd"]["count"]
+        alg = algorithmic_bytes_blend_bwd(stats["D"], H * W, stats["n_vis"])
+        achieved = alg / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "blend_bwd_kernel", "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None, "avg_kernel_ms": round(avg_ms, 4),
+                "algorithmic_bytes": int(alg)}
+    stage_ms = {k: round(v["ms"] / max(v["count"], 1), 4) for k, v in prof.items()}
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import cpu_baseline
+        cpu = cpu_baseline.run(args.splats, W, H, n_views_total)
+
+    if rank == 0:
+        out = {
+            "metric": "mapping frames/sec (render+bwd+BA) @1M splats 1920x1080",
+            "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: 1.0M splats, 8-keyframe window 1920x1080 "
+                                   "+ DBA step per GPU",
+                       "splats": args.splats, "width": W, "height": H, "views_per_gpu": V,
+                       "dba": None if dba is None else dba.describe(),
+                       "instances_D": stats["D"], "visible": stats["n_vis"],
+                       "parallelism": f"views sharded over {world} GPU(s), grad all-reduce"},
+            "roofline": roof, "cpu_baseline": cpu, "stage_ms": stage_ms,
+            "loss": None if mapper.last_loss is None else round(float(mapper.last_loss), 6),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

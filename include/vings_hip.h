@@ -145,6 +145,18 @@ int vings_sparse_adam_multi(int n_groups, float* const* params_host,
                             const float* lrs_host, const uint8_t* visible, float b1, float b2,
                             float eps, int N, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Optional per-kernel timing with HIP events on the caller's stream (no
+ * counterpart in the reference, whose only timers are the wandb brackets of
+ * /root/reference/scripts/gaussian/wandb_utils.py:30-45).  enable(1) creates
+ * an event pool once and resets the counters; read() synchronises on the
+ * recorded events and returns the summed milliseconds / launch count of a tag.
+ */
+int vings_profile_enable(int on);
+int vings_profile_num_tags(void);
+const char* vings_profile_tag_name(int tag);
+int vings_profile_read(int tag, double* total_ms, int64_t* count);
+
 #ifdef __cplusplus
 }
 #endif

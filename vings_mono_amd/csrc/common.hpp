@@ -32,6 +32,21 @@ void set_error(const char* fmt, ...);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// ---- optional per-kernel HIP-event timing (off by default) -------------------
+enum ProfTag {
+    PROF_PROJECT_FWD = 0, PROF_BIN, PROF_BLEND_FWD, PROF_BLEND_BWD, PROF_PROJECT_BWD, PROF_ADAM,
+    PROF_DBA_JAC, PROF_DBA_SCHUR, PROF_DBA_SOLVE, PROF_DBA_RETRACT, PROF_AUX, PROF_NTAGS
+};
+bool prof_enabled();
+// Record an event on `s`; the pair (begin,end) is attributed to `tag`.
+void prof_begin(int tag, hipStream_t s);
+void prof_end(int tag, hipStream_t s);
+struct ProfScope {
+    int tag; hipStream_t s; bool on;
+    ProfScope(int t, hipStream_t st) : tag(t), s(st), on(prof_enabled()) { if (on) prof_begin(tag, s); }
+    ~ProfScope() { if (on) prof_end(tag, s); }
+};
+
 // ---- wave64 primitives -----------------------------------------------------
 constexpr int kWave = 64;
 

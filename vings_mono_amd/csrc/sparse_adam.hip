@@ -78,6 +78,7 @@ extern "C" int vings_sparse_adam(float* param, const float* grad, float* exp_avg
     const int64_t total = (int64_t)N * M;
     int blocks = cdiv(total, 256);
     if (blocks > 2048) blocks = 2048;
+    ProfScope prof(PROF_ADAM, (hipStream_t)stream);
     sparse_adam_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq,
                                                                 visible, lr, b1, b2, eps, total, M);
     VINGS_LAUNCH_CHECK();
@@ -111,6 +112,7 @@ extern "C" int vings_sparse_adam_multi(int n_groups, float* const* params_host,
     }
     int blocks = cdiv(N, 256);
     if (blocks > 4096) blocks = 4096;
+    ProfScope prof(PROF_ADAM, (hipStream_t)stream);
     sparse_adam_multi_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(G, visible, b1, b2, eps, N);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;

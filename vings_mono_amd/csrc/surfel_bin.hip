@@ -244,6 +244,7 @@ extern "C" int vings_surfel_bin(int N, int H, int W, int64_t D, const float* dep
         return VINGS_ERR_CAPACITY;
     }
     const int passes = sort_passes(T);
+    ProfScope prof(PROF_BIN, s);
     // ping-pong so that the last pass lands in keys_sorted / vals_sorted
     uint64_t* kbuf[2] = {keys_sorted, b.keys_alt};
     uint32_t* vbuf[2] = {vals_sorted, b.vals_alt};

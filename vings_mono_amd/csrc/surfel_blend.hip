@@ -343,6 +343,7 @@ extern "C" int vings_surfel_blend_forward(int H, int W, const uint32_t* ranges,
     VINGS_REQUIRE(ranges && bg && out_color && allmap && final_T && n_contrib, "null pointer");
     VINGS_REQUIRE(((uintptr_t)geom & 15) == 0, "geom must be 16-byte aligned");
     const int gx = (W + 15) / 16, gy = (H + 15) / 16;
+    ProfScope prof(PROF_BLEND_FWD, (hipStream_t)stream);
     blend_fwd_kernel<<<gx * gy, 256, 0, (hipStream_t)stream>>>(
         H, W, gx, ranges, vals_sorted, geom, bg, pixel_mask, out_color, allmap, final_T, n_contrib);
     VINGS_LAUNCH_CHECK();
@@ -362,6 +363,7 @@ extern "C" int vings_surfel_blend_backward(int N, int H, int W, const uint32_t* 
     hipStream_t s = (hipStream_t)stream;
     VINGS_CHECK_HIP(hipMemsetAsync(dgeom, 0, sizeof(float) * (size_t)N * VINGS_GEOM_STRIDE, s));
     const int gx = (W + 15) / 16, gy = (H + 15) / 16;
+    ProfScope prof(PROF_BLEND_BWD, s);
     blend_bwd_kernel<<<gx * gy, 256, 0, s>>>(H, W, gx, ranges, vals_sorted, geom, bg, pixel_mask,
                                              final_T, n_contrib, dL_dcolor, dL_dallmap, dgeom);
     VINGS_LAUNCH_CHECK();

@@ -296,12 +296,15 @@ extern "C" int vings_surfel_project(int N, int H, int W, float scale_modifier,
                   "geom/rotations/rect must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int nb = cdiv(N, 256);
+    {
+    ProfScope prof(PROF_PROJECT_FWD, s);
     project_fwd_kernel<<<nb, 256, 0, s>>>(N, H, W, scale_modifier, means3D, scales, rotations,
                                           opacities, colors, flow, viewmatrix, projmatrix, geom,
                                           depth, radii, rect, tiles_touched, block_prefix);
     VINGS_LAUNCH_CHECK();
     scan_blocks_kernel<<<1, 1024, 0, s>>>(block_prefix, nb);
     VINGS_LAUNCH_CHECK();
+    }
     uint32_t total = 0;
     VINGS_CHECK_HIP(hipMemcpyAsync(&total, block_prefix + nb, sizeof(uint32_t),
                                    hipMemcpyDeviceToHost, s));
@@ -325,6 +328,7 @@ extern "C" int vings_surfel_project_backward(int N, int H, int W, float scale_mo
                       dL_dmeans3D && dL_dscales && dL_drotations && dL_dopacities && dL_dcolors,
                   "null pointer");
     hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(PROF_PROJECT_BWD, s);
     project_bwd_kernel<<<cdiv(N, 256), 256, 0, s>>>(
         N, H, W, scale_modifier, means3D, scales, rotations, viewmatrix, projmatrix, radii, dgeom,
         dL_dmeans3D, dL_dscales, dL_drotations, dL_dopacities, dL_dcolors, dL_dmeans2D,

@@ -1,0 +1,211 @@
+"""Python wrapper around the rasteriser that the mapping loop needs: render
+post-processing, the mapping loss and the score-weighted gradient step.
+
+This is the counterpart of the reference's own Python around its native
+extension (it stays PyTorch there too):
+  render post-processing  /root/reference/scripts/gaussian/gaussian_base.py:142-224
+  depth -> normal         /root/reference/scripts/gaussian/normal_utils.py:6-21
+                          /root/reference/scripts/gaussian/tf.py:133-142
+  loss                    /root/reference/scripts/gaussian/loss_utils.py:7-153
+  score weighting         /root/reference/scripts/gaussian/gaussian_utils.py:56-62
+  hot loop                /root/reference/scripts/gaussian/gaussian_base.py:343-404
+The formulas are pinned by fixtures generated from those reference functions
+(tests/golden/harness_golden.npz).  Masked means are written as weighted sums
+instead of boolean indexing so the loop never synchronises with the host.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import synth
+from .surfel import GaussianRasterizationSettings, GaussianRasterizer, SparseGaussianAdam
+
+# training_args of /root/reference/configs/hierarchical/smallcity.yaml:67-81
+DEFAULT_LR = {"_xyz_lr": 0.00016, "_rgb_lr": 0.0025, "_opacity_lr": 0.05, "_scaling_lr": 0.005,
+              "_rotation_lr": 0.001}
+DEFAULT_LOSS_WEIGHTS = {"rgb_loss": 1.0, "depth_loss": 1.0, "alpha_loss": 1.0,
+                        "normal_loss": 0.1, "dist_loss": 0.0}
+
+
+def backproject_depth(depth, intr):
+    """(H,W) depth -> (H,W,3) camera-space points; u = row (vertical), v = column."""
+    H, W = depth.shape
+    u = torch.arange(H, device=depth.device, dtype=depth.dtype).view(H, 1)
+    v = torch.arange(W, device=depth.device, dtype=depth.dtype).view(1, W)
+    x = (v - intr["cv"]) / intr["fv"] * depth
+    y = (u - intr["cu"]) / intr["fu"] * depth
+    return torch.stack((x, y, depth), dim=-1)
+
+
+def depth_to_normal(depth, intr):
+    """Camera-space surface normal from a depth map by central differences; zero border."""
+    pts = backproject_depth(depth, intr)
+    dx = pts[1:-1, 2:] - pts[1:-1, :-2]
+    dy = pts[:-2, 1:-1] - pts[2:, 1:-1]
+    n = F.normalize(torch.cross(dx, dy, dim=-1), p=2, dim=-1)
+    return F.pad(n, (0, 0, 1, 1, 1, 1))
+
+
+def render(params, w2c, intr, bg=None, pixel_mask=None, u2_minus_u1=None, scores=None,
+           means2D=None):
+    """Render one view; returns the dict consumed by the loss (gaussian_base.py:211-224)."""
+    dev = params["_xyz"].device
+    cam = synth.Camera(w2c, intr)
+    if bg is None:
+        bg = torch.zeros(3, device=dev)
+    settings = GaussianRasterizationSettings(
+        image_height=cam.height, image_width=cam.width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+        bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+        projmatrix=cam.full_proj_transform, sh_degree=0, campos=cam.camera_center,
+        prefiltered=False, debug=False, pixel_mask=pixel_mask, u2_minus_u1=u2_minus_u1)
+    act = synth.activate(params)
+    rgb, radii, allmap = GaussianRasterizer(raster_settings=settings)(
+        means3D=act["means3D"], means2D=means2D, shs=None, colors_precomp=act["colors"],
+        opacities=act["opacities"], scales=act["scales"], rotations=act["rotations"],
+        scores=scores, cov3D_precomp=None)
+    return postprocess(rgb, radii, allmap, w2c, intr)
+
+
+def postprocess(rgb, radii, allmap, w2c, intr):
+    alpha = allmap[1:2]
+    depth = torch.nan_to_num(allmap[0:1] / alpha, 0, 0)
+    Rw2c = w2c[:3, :3]
+    normal = (allmap[2:5].permute(1, 2, 0) @ Rw2c).permute(2, 0, 1)
+    surf = depth_to_normal(depth.squeeze(0), intr)
+    surf = (surf @ Rw2c).permute(2, 0, 1)
+    return {"radii": radii, "accum": alpha, "rgb": rgb, "depth": depth, "normal": normal,
+            "dist": allmap[6:7], "surf_normal": surf, "flow": allmap[7:9]}
+
+
+_WINDOWS = {}
+
+
+def _ssim_window(channel, device, dtype):
+    key = (channel, str(device), dtype)
+    if key not in _WINDOWS:
+        g = torch.tensor([math.exp(-(x - 5) ** 2 / (2 * 1.5 ** 2)) for x in range(11)])
+        g = (g / g.sum()).unsqueeze(1)
+        w2 = (g @ g.t()).float()[None, None].expand(channel, 1, 11, 11).contiguous()
+        _WINDOWS[key] = w2.to(device=device, dtype=dtype)
+    return _WINDOWS[key]
+
+
+def ssim_map(img1, img2):
+    c = img1.shape[-3]
+    w = _ssim_window(c, img1.device, img1.dtype)
+    mu1 = F.conv2d(img1, w, padding=5, groups=c)
+    mu2 = F.conv2d(img2, w, padding=5, groups=c)
+    mu1_sq, mu2_sq, mu12 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    s1 = F.conv2d(img1 * img1, w, padding=5, groups=c) - mu1_sq
+    s2 = F.conv2d(img2 * img2, w, padding=5, groups=c) - mu2_sq
+    s12 = F.conv2d(img1 * img2, w, padding=5, groups=c) - mu12
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    return ((2 * mu12 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))
+
+
+def _masked_mean(x, mask_f, count):
+    # mean over the selected pixels of all channels of x ([C,H,W])
+    return (x * mask_f).sum() / (count * x.shape[0])
+
+
+def mapping_loss(pred, gt, weights=DEFAULT_LOSS_WEIGHTS):
+    """Total mapping loss (use_sky = False branch of loss_utils.get_loss)."""
+    sky = gt["rgb"].sum(dim=0) == 0.0
+    valid = (~sky) & (gt["depth"].sum(dim=0) > 0.0)
+    vf, sf = valid.to(pred["rgb"].dtype), sky.to(pred["rgb"].dtype)
+    nv, ns = vf.sum().clamp(min=1.0), sf.sum().clamp(min=1.0)
+    l1 = _masked_mean((pred["rgb"] - gt["rgb"]).abs(), vf, nv)
+    ssim = _masked_mean(ssim_map(pred["rgb"], gt["rgb"]), vf, nv)
+    rgb_loss = 0.8 * l1 + 0.2 * (1.0 - ssim)
+    normal_loss = ((1 - (pred["normal"] * pred["surf_normal"]).sum(dim=0)) * vf).sum() / nv
+    alpha_loss = _masked_mean(pred["accum"], sf, ns)
+    depth_loss = _masked_mean((pred["depth"] - gt["depth"]).abs() / gt["depth_cov"], vf, nv)
+    dist_loss = _masked_mean(pred["dist"], vf, nv)
+    return (weights["rgb_loss"] * rgb_loss + weights["normal_loss"] * normal_loss +
+            weights["alpha_loss"] * alpha_loss + weights["depth_loss"] * depth_loss +
+            weights["dist_loss"] * dist_loss)
+
+
+def score_weight(current_scores, global_scores):
+    """Per-splat gradient weight s0 / (S0 + 1e-6 + s0), [N,1]."""
+    s0 = current_scores[:, 0]
+    return (s0 / (global_scores[:, 0] + 1e-6 + s0)).unsqueeze(1)
+
+
+class SurfelMapper:
+    """Splat parameter store + the per-view optimisation step of the mapping loop."""
+
+    NAMES = ("_xyz", "_rgb", "_opacity", "_scaling", "_rotation")
+
+    def __init__(self, raw_params, device, lr=DEFAULT_LR, loss_weights=DEFAULT_LOSS_WEIGHTS):
+        self.device = torch.device(device)
+        self.params = {k: torch.nn.Parameter(raw_params[k].to(self.device).float().contiguous())
+                       for k in self.NAMES}
+        n = self.params["_xyz"].shape[0]
+        self.n = n
+        self.loss_weights = dict(loss_weights)
+        groups = [{"params": [self.params[k]], "lr": lr[k + "_lr"], "name": k} for k in self.NAMES]
+        self.optimizer = SparseGaussianAdam(groups, lr=0.0, eps=1e-15)
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=self.device)
+        self.global_scores = z(n, 2)
+        self.local_scores = z(n, 2)
+        self.stable_mask = z(n, dt=torch.bool)
+        self.globalkf_id = z(n, dt=torch.int64)
+        self.globalkf_max_scores = z(n)
+        self.last_loss = None
+
+    def render(self, w2c, intr, scores=None):
+        return render(self.params, w2c, intr, scores=scores)
+
+    def backward_view(self, w2c, intr, gt):
+        """Forward + loss + backward for one view; leaves .grad on the parameters.
+        Returns (radii, current_scores)."""
+        scores = torch.zeros((self.n, 2), device=self.device, requires_grad=True)
+        pred = self.render(w2c, intr, scores=scores)
+        loss = mapping_loss(pred, gt, self.loss_weights)
+        loss.backward()
+        self.last_loss = loss.detach()
+        return pred["radii"], scores.grad.detach()
+
+    def finish_view(self, radii, cur, kf_id, reducer=None):
+        """Score bookkeeping, gradient weighting, (multi-GPU) gradient exchange and the
+        sparse Adam step for one view (gaussian_base.py:385-403,
+        gaussian_model.py:163-168).  With one rank this is exactly the reference order:
+        record the scores, weight every gradient by s0 / (S0 + 1e-6 + s0) using the updated
+        global score, zero the radii of stable splats, step."""
+        s0 = cur[:, 0]
+        g0_local = (self.global_scores[:, 0] + s0).clamp(0.0, 1e4)
+        w = (s0 / (g0_local + 1e-6 + s0)).unsqueeze(1)
+        grads = {k: self.params[k].grad for k in self.NAMES}
+        for k in self.NAMES:
+            grads[k].mul_(w)
+        vis = (radii > 0) & (~self.stable_mask)
+        if reducer is not None and reducer.world > 1:
+            vis, s0_sum, s1_max, best, best_kf = reducer.reduce(grads, cur, vis, kf_id)
+        else:
+            s0_sum, s1_max, best = s0, cur[:, 1], s0
+            best_kf = torch.full_like(self.globalkf_id, kf_id)
+        self.local_scores[:, 0] += s0_sum
+        self.global_scores[:, 0] = (self.global_scores[:, 0] + s0_sum).clamp(0.0, 1e4)
+        self.local_scores[:, 1] = torch.maximum(self.local_scores[:, 1], s1_max)
+        replace = self.globalkf_max_scores < best
+        self.globalkf_max_scores = torch.where(replace, best, self.globalkf_max_scores)
+        self.globalkf_id = torch.where(replace, best_kf, self.globalkf_id)
+        self.optimizer.step(vis, self.n)
+        self.optimizer.zero_grad(set_to_none=False)
+        self._last_radii = radii
+
+    def train_view(self, c2w, intr, gt, kf_id=0, reducer=None):
+        """One iteration of the reference's hot loop (gaussian_base.py:353-404)."""
+        w2c = torch.linalg.inv(c2w)
+        radii, cur = self.backward_view(w2c, intr, gt)
+        self.finish_view(radii, cur, kf_id, reducer)
+        return self.last_loss
+
+    def last_stats(self):
+        """Instance count D and visible-splat count of the most recent forward pass."""
+        from . import surfel
+        n_vis = int((self._last_radii > 0).sum().item()) if getattr(self, "_last_radii", None) \
+            is not None else 0
+        return {"D": int(surfel.LAST_INSTANCE_COUNT), "n_vis": n_vis}

@@ -16,6 +16,7 @@ from . import _lib
 from ._lib import check, ptr, stream_ptr
 
 GEOM_STRIDE = 20
+LAST_INSTANCE_COUNT = 0  # D of the most recent forward pass (diagnostics)
 AUX_CHANNELS = 9
 TILE = 16
 
@@ -91,6 +92,8 @@ def rasterize_forward(means3D, colors, opacities, scales, rotations, settings, k
         ctypes.byref(d_host), stream), "vings_surfel_project")
     D = int(d_host.value)
     st.D = D
+    global LAST_INSTANCE_COUNT
+    LAST_INSTANCE_COUNT = D
     T = ((W + TILE - 1) // TILE) * ((H + TILE - 1) // TILE)
     st.keys = torch.empty(max(D, 1), dtype=torch.int64, device=dev)
     st.vals = torch.empty(max(D, 1), dtype=torch.int32, device=dev)
