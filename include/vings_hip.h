@@ -145,6 +145,99 @@ int vings_sparse_adam_multi(int n_groups, float* const* params_host,
                             const float* lrs_host, const uint8_t* visible, float b1, float b2,
                             float eps, int N, void* stream);
 
+/* ========================================================================
+ * Dense bundle adjustment (droid_backends).
+ *
+ * Shapes as passed by the reference (depth_video.py:380-381, 654-659):
+ *   poses[B,7] (tx,ty,tz,qx,qy,qz,qw; world->camera)   disps[B,ht,wd]
+ *   intr[4] = fx,fy,cx,cy at grid resolution             disps_sens[B,ht,wd] or NULL
+ *   target, weight [E,2,ht,wd]   eta[M,ht,wd]   ii, jj [E] int64 (device)
+ * Poses t0 <= f < t1 are free (P = t1-t0); the M depth variables are the
+ * sorted unique of arange(t0,t1) and ii, so M equals the row count of eta.
+ * All state between stages lives in one caller-provided workspace whose
+ * layout is returned by vings_dba_layout_query (byte offsets).
+ * ======================================================================== */
+typedef struct vings_dba_layout {
+    size_t total_bytes;
+    size_t off_E;         /* double [(P+E),6,HW] coupling rows: P per-pose rows, then per edge */
+    size_t off_Q;         /* double [M,HW] inverse of the depth block                     */
+    size_t off_w;         /* double [M,HW] depth residual                                */
+    size_t off_H;         /* double [6P,6P] undamped pose block                          */
+    size_t off_v;         /* double [6P]                                                 */
+    size_t off_S;         /* double [6P,6P] Schur complement E Q E^T                     */
+    size_t off_u;         /* double [6P]    E Q w                                        */
+    size_t off_dx;        /* double [6P]    pose update                                  */
+    size_t off_chol;      /* double [6P,6P] factorisation scratch                        */
+    size_t off_kx;        /* int32  [M] frame of each depth variable                     */
+    size_t off_kk;        /* int32  [E] depth variable of each edge                      */
+    size_t off_kstart;    /* int32  [M+1] edge list offsets                              */
+    size_t off_kedges;    /* int32  [E]                                                  */
+    size_t off_ip;        /* int32  [E] ii                                               */
+    size_t off_jp;        /* int32  [E] jj                                               */
+    size_t off_ent_start; /* int32  [M+1] entry list offsets                             */
+    size_t off_ent_row;   /* int32  [P+E] row block of E                                 */
+    size_t off_ent_pose;  /* int32  [P+E] free-pose index of that row block              */
+    size_t off_status;    /* int32  [4]: depth variables found, Cholesky failed, bad index */
+} vings_dba_layout;
+
+int vings_dba_layout_query(int ht, int wd, int E, int P, int M, vings_dba_layout* out);
+
+/* droid_backends.ba (depth_video.py:380-381): `itrs` damped Gauss-Newton
+ * iterations, poses[t0:t1] and disps updated IN PLACE.  Damping
+ * H + (ep + lm*diag H) I, Schur elimination of the depth block, float64
+ * Cholesky on the device; a failed factorisation leaves that iteration's
+ * update at zero (chol.py:9-17). */
+int vings_dba_ba(float* poses, float* disps, const float* intr, const float* disps_sens,
+                 const float* target, const float* weight, const float* eta, const int64_t* ii,
+                 const int64_t* jj, int B, int ht, int wd, int E, int M, int t0, int t1, int itrs,
+                 float lm, float ep, int motion_only, void* workspace, size_t workspace_bytes,
+                 void* stream);
+
+/* BACore.init (depth_video.py:475-477,554): Jacobian stage + accumulation +
+ * Schur complement, left in the workspace. */
+int vings_dba_linearize(const float* poses, const float* disps, const float* intr,
+                        const float* disps_sens, const float* target, const float* weight,
+                        const float* eta, const int64_t* ii, const int64_t* jj, int B, int ht,
+                        int wd, int E, int M, int t0, int t1, int motion_only, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* BACore.hessian (depth_video.py:478-481,550-551,618): reduced camera system
+ * H_out[6P,6P] = H - S, v_out[6P] = v - u (float64, DEVICE buffers; the
+ * Python mirror copies them into the caller's CPU tensors). */
+int vings_dba_reduced_system(int B, int ht, int wd, int E, int M, int t0, int t1, void* workspace,
+                             size_t workspace_bytes, double* H_out, double* v_out, void* stream);
+
+/* BACore.hessian_expand (depth_video.py:568, consumed at 703-714): float32
+ * copies Q_out[M,HW] and E_out[(P+E),6,HW] (first P row blocks = coupling of
+ * each free pose with its own depth map, then one block per edge = coupling of
+ * pose jj with the depth map of ii; blocks of fixed poses are zero). */
+int vings_dba_export(int B, int ht, int wd, int E, int M, int t0, int t1, void* workspace,
+                     size_t workspace_bytes, float* Q_out, float* E_out, void* stream);
+
+/* BACore.retract (depth_video.py:649-650): applies pose update dx[6P]
+ * (float64, device; NULL = use the update stored by the solver) and the
+ * back-substituted depth update to poses / disps in place. */
+int vings_dba_retract(float* poses, float* disps, const double* dx, int B, int ht, int wd, int E,
+                      int M, int t0, int t1, int motion_only, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* droid_backends.frame_distance (depth_video.py:289-299): mean induced flow
+ * magnitude per candidate edge, beta-weighted mix of full motion and
+ * translation only; pairs with < 75 % valid weight return 1000. out[E]. */
+int vings_frame_distance(const float* poses, const float* disps, const float* intr,
+                         const int64_t* ii, const int64_t* jj, int B, int ht, int wd, int E,
+                         float beta, float* out, void* stream);
+
+/* droid_backends.corr_index_forward / _backward (modules/corr.py:12,19):
+ * bilinear lookup of a (2r+1)^2 window around coords[E,2,h1,w1] in
+ * volume[E,h1,w1,h2,w2] -> corr[E,2r+1,2r+1,h1,w1]; backward scatters
+ * corr_grad into volume_grad (zeroed by the call).  half != 0: volume and
+ * corr are float16 (the reference runs this under autocast). */
+int vings_corr_index_forward(const void* volume, const float* coords, void* corr, int E, int h1,
+                             int w1, int h2, int w2, int r, int half, void* stream);
+int vings_corr_index_backward(const float* coords, const void* corr_grad, void* volume_grad, int E,
+                              int h1, int w1, int h2, int w2, int r, int half, void* stream);
+
 /* ------------------------------------------------------------------------
  * Optional per-kernel timing with HIP events on the caller's stream (no
  * counterpart in the reference, whose only timers are the wandb brackets of

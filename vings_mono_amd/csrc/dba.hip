@@ -1,0 +1,751 @@
+// Dense bundle adjustment (DBA) core for gfx950.
+//
+// One Gauss-Newton iteration =
+//   index      : depth variables kx = unique(arange(t0,t1) U ii), per-variable
+//                edge lists and (row, pose) entry lists          (1 workgroup)
+//   linearize  : fused reprojection + Jacobians + accumulation BY SOURCE
+//                FRAME: a workgroup owns 256 pixels of one depth variable and
+//                walks all edges leaving that frame, so the depth block C, the
+//                depth residual w and the pose/depth coupling of the source
+//                pose are reduced in registers (no per-edge intermediates, no
+//                scatter pass); 6x6 pose blocks are wave-reduced and added to
+//                a float64 accumulator
+//   schur      : S = E Q E^T and u = E Q w as an MFMA block GEMM
+//                (v_mfma_f64_16x16x4_f64) over the pixel axis, block sparsity
+//                taken from the entry lists
+//   solve      : damped Cholesky of H - S in one workgroup (LDS)
+//   retract    : dz = Q (w - E^T dx), inverse depths and poses updated in place
+//
+// Everything after the float32 inputs is float64.  Monocular BA is gauge
+// deficient (scale): with ep = 0.1 against pose-block entries of ~1e4 the
+// reduced system amplifies evaluation noise by ~1e5, so float32 Jacobians
+// cannot deliver pose updates to 1e-4 relative; CDNA4's full-rate float64
+// vector and matrix units make the float64 path affordable (the whole step
+// is a few hundred MB of traffic and < 1 GFLOP).
+//
+// Serves droid_backends.ba / BACore as called at
+// /root/reference/scripts/frontend/depth_video.py:380-381,475-481,550-568,649-650;
+// the mathematics follow /root/reference/scripts/frontend/geom/ba.py:29-104,
+// chol.py:32-73 and projective_ops.py:18-125.
+#include "common.hpp"
+
+namespace vings {
+
+constexpr double kMinDepth = 0.2;
+constexpr double kSensorAlpha = 0.05;
+constexpr int kMaxFrames = 4096;
+
+struct DbaWs {  // typed view of the caller's workspace
+    double* E;       // [(P+E),6,HW]
+    double* Q;       // [M,HW]
+    double* w;       // [M,HW]
+    double* H;       // [6P,6P]
+    double* v;       // [6P]
+    double* S;       // [6P,6P]
+    double* u;       // [6P]
+    double* dx;      // [6P]
+    double* chol;    // [6P,6P]
+    int* kx;         // [M]
+    int* kk;         // [E]
+    int* kstart;     // [M+1]
+    int* kedges;     // [E]
+    int* ip;         // [E]
+    int* jp;         // [E]
+    int* ent_start;  // [M+1]
+    int* ent_row;    // [P+E]
+    int* ent_pose;   // [P+E]
+    int* status;     // [4]
+};
+
+static size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static void layout(int ht, int wd, int E, int P, int M, vings_dba_layout* L) {
+    const size_t HW = (size_t)ht * wd;
+    const size_t n = 6 * (size_t)P;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += up256(bytes); return r; };
+    L->off_E = take(sizeof(double) * (size_t)(P + E) * 6 * HW);
+    L->off_Q = take(sizeof(double) * (size_t)M * HW);
+    L->off_w = take(sizeof(double) * (size_t)M * HW);
+    L->off_H = take(sizeof(double) * n * n);
+    L->off_v = take(sizeof(double) * n);
+    L->off_S = take(sizeof(double) * n * n);
+    L->off_u = take(sizeof(double) * n);
+    L->off_dx = take(sizeof(double) * n);
+    L->off_chol = take(sizeof(double) * n * n);
+    L->off_kx = take(sizeof(int) * (size_t)(M + 1));
+    L->off_kk = take(sizeof(int) * (size_t)(E + 1));
+    L->off_kstart = take(sizeof(int) * (size_t)(M + 2));
+    L->off_kedges = take(sizeof(int) * (size_t)(E + 1));
+    L->off_ip = take(sizeof(int) * (size_t)(E + 1));
+    L->off_jp = take(sizeof(int) * (size_t)(E + 1));
+    L->off_ent_start = take(sizeof(int) * (size_t)(M + 2));
+    L->off_ent_row = take(sizeof(int) * (size_t)(P + E + 1));
+    L->off_ent_pose = take(sizeof(int) * (size_t)(P + E + 1));
+    L->off_status = take(sizeof(int) * 4);
+    L->total_bytes = o;
+}
+
+static DbaWs carve(void* ws, const vings_dba_layout& L) {
+    char* p = (char*)ws;
+    DbaWs W;
+    W.E = (double*)(p + L.off_E); W.Q = (double*)(p + L.off_Q); W.w = (double*)(p + L.off_w);
+    W.H = (double*)(p + L.off_H); W.v = (double*)(p + L.off_v); W.S = (double*)(p + L.off_S);
+    W.u = (double*)(p + L.off_u); W.dx = (double*)(p + L.off_dx); W.chol = (double*)(p + L.off_chol);
+    W.kx = (int*)(p + L.off_kx); W.kk = (int*)(p + L.off_kk); W.kstart = (int*)(p + L.off_kstart);
+    W.kedges = (int*)(p + L.off_kedges); W.ip = (int*)(p + L.off_ip); W.jp = (int*)(p + L.off_jp);
+    W.ent_start = (int*)(p + L.off_ent_start); W.ent_row = (int*)(p + L.off_ent_row);
+    W.ent_pose = (int*)(p + L.off_ent_pose); W.status = (int*)(p + L.off_status);
+    return W;
+}
+
+// ---------------------------------------------------------------------------
+// SE3 helpers, quaternion (x,y,z,w)
+// ---------------------------------------------------------------------------
+struct Se3d { double t[3]; double q[4]; };
+
+__device__ __forceinline__ void qrot(const double* q, const double* v, double* o) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double tx = 2 * (y * v[2] - z * v[1]), ty = 2 * (z * v[0] - x * v[2]),
+                 tz = 2 * (x * v[1] - y * v[0]);
+    o[0] = v[0] + w * tx + (y * tz - z * ty);
+    o[1] = v[1] + w * ty + (z * tx - x * tz);
+    o[2] = v[2] + w * tz + (x * ty - y * tx);
+}
+__device__ __forceinline__ void qmul(const double* a, const double* b, double* o) {
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+    o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+// G_ij = G_j * G_i^-1 ; a self edge is the fixed stereo baseline (projective_ops.py:105)
+__device__ __forceinline__ Se3d relative_pose(const float* __restrict__ poses, int i, int j) {
+    Se3d G;
+    if (i == j) {
+        G.t[0] = -0.1; G.t[1] = 0.; G.t[2] = 0.;
+        G.q[0] = G.q[1] = G.q[2] = 0.; G.q[3] = 1.;
+        return G;
+    }
+    const float* pi = poses + 7 * i;
+    const float* pj = poses + 7 * j;
+    const double qi_inv[4] = {-(double)pi[3], -(double)pi[4], -(double)pi[5], (double)pi[6]};
+    const double qj[4] = {pj[3], pj[4], pj[5], pj[6]};
+    qmul(qj, qi_inv, G.q);
+    double rt[3];
+    const double ti[3] = {pi[0], pi[1], pi[2]};
+    qrot(G.q, ti, rt);
+    G.t[0] = (double)pj[0] - rt[0]; G.t[1] = (double)pj[1] - rt[1]; G.t[2] = (double)pj[2] - rt[2];
+    return G;
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// index kernel
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dba_index_kernel(const int64_t* __restrict__ ii,
+                                                        const int64_t* __restrict__ jj, int B, int E,
+                                                        int M, int t0, int t1, DbaWs W) {
+    __shared__ int flag[kMaxFrames];
+    __shared__ int pos[kMaxFrames];
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    if (tid == 0) bad = 0;
+    for (int f = tid; f < B; f += 256) flag[f] = (f >= t0 && f < t1) ? 1 : 0;
+    __syncthreads();
+    for (int e = tid; e < E; e += 256) {
+        const long a = ii[e], b = jj[e];
+        if (a < 0 || a >= B || b < 0 || b >= B) { bad = 1; W.ip[e] = 0; W.jp[e] = 0; continue; }
+        W.ip[e] = (int)a; W.jp[e] = (int)b;
+        flag[a] = 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int c = 0;
+        for (int f = 0; f < B; ++f) {
+            pos[f] = c;
+            if (flag[f]) { if (c < M) W.kx[c] = f; ++c; }
+        }
+        W.status[0] = c;                 // number of depth variables found
+        W.status[1] = 0;                 // cholesky failure flag
+        W.status[2] = bad;               // index out of range / eta row count mismatch
+        if (c != M) bad = 1;
+    }
+    __syncthreads();
+    if (bad) {  // leave empty lists: every later kernel becomes a no-op
+        for (int k = tid; k <= M; k += 256) { W.kstart[k] = 0; W.ent_start[k] = 0; }
+        if (tid == 0) W.status[2] = 1;
+        return;
+    }
+    for (int e = tid; e < E; e += 256) W.kk[e] = pos[W.ip[e]];
+    __syncthreads();
+    // per depth variable: edge list (in edge order) and entry list
+    if (tid == 0) {
+        int ce = 0, cn = 0;
+        for (int k = 0; k < M; ++k) {
+            W.kstart[k] = ce;
+            W.ent_start[k] = cn;
+            const int f = W.kx[k];
+            if (f >= t0 && f < t1) { W.ent_row[cn] = f - t0; W.ent_pose[cn] = f - t0; ++cn; }
+            for (int e = 0; e < E; ++e) {
+                if (W.ip[e] != f) continue;
+                W.kedges[ce++] = e;
+                const int j = W.jp[e];
+                if (j >= t0 && j < t1) { W.ent_row[cn] = (t1 - t0) + e; W.ent_pose[cn] = j - t0; ++cn; }
+            }
+        }
+        W.kstart[M] = ce;
+        W.ent_start[M] = cn;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// linearize
+// ---------------------------------------------------------------------------
+constexpr int kNH = 21 + 36 + 21 + 6 + 6;  // Hii(upper) Hij Hjj(upper) vi vj
+
+__device__ __forceinline__ constexpr int tri(int a, int b) {  // (a<=b) in a 6x6 upper triangle
+    return a * 6 - a * (a - 1) / 2 + (b - a);
+}
+
+__global__ __launch_bounds__(256) void dba_linearize_kernel(
+    const float* __restrict__ poses, const float* __restrict__ disps,
+    const float* __restrict__ intr, const float* __restrict__ disps_sens,
+    const float* __restrict__ target, const float* __restrict__ weight,
+    const float* __restrict__ eta, int ht, int wd, int E, int M, int t0, int t1, int motion_only,
+    DbaWs W) {
+    __shared__ double red[4][kNH];
+    const int k = blockIdx.y;
+    const int HW = ht * wd;
+    const int P = t1 - t0;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const bool act = p < HW;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int e0 = W.kstart[k], e1 = W.kstart[k + 1];
+    if (W.status[2]) return;
+    if (motion_only && e0 == e1) return;
+    const int i = W.kx[k];
+    const double fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+    const int pu = act ? p % wd : 0, pvv = act ? p / wd : 0;
+    const double d = act ? (double)disps[(size_t)i * HW + p] : 1.0;
+    const double X0[3] = {((double)pu - cx) / fx, ((double)pvv - cy) / fy, 1.0};
+    const bool i_free = i >= t0 && i < t1;
+    double Cacc = 0., wacc = 0., Ei[6] = {0, 0, 0, 0, 0, 0};
+
+    for (int idx = e0; idx < e1; ++idx) {
+        const int e = W.kedges[idx];
+        const int j = W.jp[e];
+        const bool j_free = j >= t0 && j < t1;
+        const Se3d G = relative_pose(poses, i, j);
+        double X1[3];
+        qrot(G.q, X0, X1);
+        X1[0] += G.t[0] * d; X1[1] += G.t[1] * d; X1[2] += G.t[2] * d;
+        const double Z = X1[2];
+        const bool valid = act && Z > kMinDepth;
+        const double dz = 1.0 / (Z < 0.5 * kMinDepth ? 1.0 : Z);
+        const double xn = X1[0] * dz, yn = X1[1] * dz;
+        double r[2] = {0, 0}, wt[2] = {0, 0};
+        if (valid) {
+            const size_t o = ((size_t)e * 2) * HW + p;
+            r[0] = (double)target[o] - (fx * xn + cx);
+            r[1] = (double)target[o + HW] - (fy * yn + cy);
+            wt[0] = 0.001 * (double)weight[o];
+            wt[1] = 0.001 * (double)weight[o + HW];
+        }
+        // rows of d(coords)/d(xi_j), twist ordered (tau, phi)
+        double Jj[2][6], Ji[2][6], Jz[2];
+        const double h = d;
+        Jj[0][0] = fx * h * dz; Jj[0][1] = 0.; Jj[0][2] = -fx * xn * h * dz;
+        Jj[0][3] = -fx * xn * yn; Jj[0][4] = fx * (1. + xn * xn); Jj[0][5] = -fx * yn;
+        Jj[1][0] = 0.; Jj[1][1] = fy * h * dz; Jj[1][2] = -fy * yn * h * dz;
+        Jj[1][3] = -fy * (1. + yn * yn); Jj[1][4] = fy * xn * yn; Jj[1][5] = fy * xn;
+        Jz[0] = fx * (G.t[0] * dz - G.t[2] * xn * dz);
+        Jz[1] = fy * (G.t[1] * dz - G.t[2] * yn * dz);
+        // Ji = -Jj * Ad(G): for a row (a | b): tau part R^T a, phi part R^T (b + a x t)
+        const double qinv[4] = {-G.q[0], -G.q[1], -G.q[2], G.q[3]};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const double a[3] = {Jj[c][0], Jj[c][1], Jj[c][2]};
+            const double b[3] = {Jj[c][3], Jj[c][4], Jj[c][5]};
+            double ra[3], rb[3];
+            qrot(qinv, a, ra);
+            const double s[3] = {b[0] + (a[1] * G.t[2] - a[2] * G.t[1]),
+                                 b[1] + (a[2] * G.t[0] - a[0] * G.t[2]),
+                                 b[2] + (a[0] * G.t[1] - a[1] * G.t[0])};
+            qrot(qinv, s, rb);
+            Ji[c][0] = -ra[0]; Ji[c][1] = -ra[1]; Ji[c][2] = -ra[2];
+            Ji[c][3] = -rb[0]; Ji[c][4] = -rb[1]; Ji[c][5] = -rb[2];
+        }
+        if (!motion_only) {
+            Cacc += wt[0] * Jz[0] * Jz[0] + wt[1] * Jz[1] * Jz[1];
+            wacc += wt[0] * r[0] * Jz[0] + wt[1] * r[1] * Jz[1];
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+                Ei[m] += wt[0] * Ji[0][m] * Jz[0] + wt[1] * Ji[1][m] * Jz[1];
+                if (act && j_free)
+                    W.E[((size_t)(P + e) * 6 + m) * HW + p] =
+                        wt[0] * Jj[0][m] * Jz[0] + wt[1] * Jj[1][m] * Jz[1];
+            }
+        }
+        if (!i_free && !j_free) continue;  // both poses fixed: nothing for the pose block
+        double hacc[kNH];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+            for (int b = a; b < 6; ++b) {
+                hacc[tri(a, b)] = wt[0] * Ji[0][a] * Ji[0][b] + wt[1] * Ji[1][a] * Ji[1][b];
+                hacc[57 + tri(a, b)] = wt[0] * Jj[0][a] * Jj[0][b] + wt[1] * Jj[1][a] * Jj[1][b];
+            }
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+                hacc[21 + a * 6 + b] = wt[0] * Ji[0][a] * Jj[0][b] + wt[1] * Ji[1][a] * Jj[1][b];
+            hacc[78 + a] = wt[0] * Ji[0][a] * r[0] + wt[1] * Ji[1][a] * r[1];
+            hacc[84 + a] = wt[0] * Jj[0][a] * r[0] + wt[1] * Jj[1][a] * r[1];
+        }
+#pragma unroll
+        for (int q = 0; q < kNH; ++q) {
+            const double s = wave_sum_f64(hacc[q]);
+            if (lane == 0) red[wv][q] = s;
+        }
+        __syncthreads();
+        const int n6 = 6 * P;
+        const int ib = (i - t0) * 6, jb = (j - t0) * 6;
+        for (int q = threadIdx.x; q < kNH; q += 256) {
+            const double s = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+            if (s == 0.0) continue;
+            if (q < 21) {  // Hii upper
+                if (!i_free) continue;
+                int a = 0, rem = q;
+                while (rem >= 6 - a) { rem -= 6 - a; ++a; }
+                const int b = a + rem;
+                atomicAdd(&W.H[(size_t)(ib + a) * n6 + ib + b], s);
+                if (a != b) atomicAdd(&W.H[(size_t)(ib + b) * n6 + ib + a], s);
+            } else if (q < 57) {  // Hij and its transpose Hji
+                if (!(i_free && j_free)) continue;
+                const int a = (q - 21) / 6, b = (q - 21) % 6;
+                atomicAdd(&W.H[(size_t)(ib + a) * n6 + jb + b], s);
+                atomicAdd(&W.H[(size_t)(jb + b) * n6 + ib + a], s);
+            } else if (q < 78) {  // Hjj upper
+                if (!j_free) continue;
+                int a = 0, rem = q - 57;
+                while (rem >= 6 - a) { rem -= 6 - a; ++a; }
+                const int b = a + rem;
+                atomicAdd(&W.H[(size_t)(jb + a) * n6 + jb + b], s);
+                if (a != b) atomicAdd(&W.H[(size_t)(jb + b) * n6 + jb + a], s);
+            } else if (q < 84) {
+                if (i_free) atomicAdd(&W.v[ib + (q - 78)], s);
+            } else {
+                if (j_free) atomicAdd(&W.v[jb + (q - 84)], s);
+            }
+        }
+        __syncthreads();
+    }
+    if (motion_only || !act) return;
+    if (i_free) {
+#pragma unroll
+        for (int m = 0; m < 6; ++m) W.E[((size_t)(i - t0) * 6 + m) * HW + p] = Ei[m];
+    }
+    const size_t fo = (size_t)i * HW + p;
+    const double ds = disps_sens ? (double)disps_sens[fo] : 0.;
+    const bool sens = ds > 0.;
+    const double C = Cacc + (sens ? kSensorAlpha : (double)eta[(size_t)k * HW + p]);
+    const double wr = wacc - (sens ? kSensorAlpha * (d - ds) : 0.);
+    W.Q[(size_t)k * HW + p] = 1.0 / C;
+    W.w[(size_t)k * HW + p] = wr;
+}
+
+// ---------------------------------------------------------------------------
+// Schur complement as an MFMA block GEMM.
+// For depth variable k the rows of Y are its entries' 6 coupling rows plus the
+// residual row w; G = (Y diag(Q)) Y^T is accumulated in 16x16 f64 MFMA tiles
+// over a slice of the pixel axis and scattered (float64 atomics) into S and u.
+// Operand map of v_mfma_f64_16x16x4_f64: lane l holds A[l&15][l>>4] and
+// B[l>>4][l&15]; result reg r of lane l is C[(l>>4) + 4r][l&15].
+// ---------------------------------------------------------------------------
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+constexpr int kSchurSlice = 512;
+
+__global__ __launch_bounds__(256) void dba_schur_kernel(int HW, int P, DbaWs W) {
+    const int k = blockIdx.y;
+    if (W.status[2]) return;
+    const int n0 = W.ent_start[k], n1 = W.ent_start[k + 1];
+    const int nent = n1 - n0;
+    if (nent == 0) return;
+    const int nrows = 6 * nent + 1;
+    const int R16 = (nrows + 15) / 16;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int k0 = blockIdx.x * kSchurSlice;
+    const int k1 = min(HW, k0 + kSchurSlice);
+    const double* Qk = W.Q + (size_t)k * HW;
+    const int n6 = 6 * P;
+
+    auto row_ptr = [&](int rho) -> const double* {
+        if (rho >= nrows) return nullptr;
+        if (rho == nrows - 1) return W.w + (size_t)k * HW;
+        const int ent = rho / 6, c = rho - ent * 6;
+        return W.E + ((size_t)W.ent_row[n0 + ent] * 6 + c) * HW;
+    };
+
+    for (int t = wv; t < R16 * R16; t += 4) {
+        const int rb = t / R16, cb = t - rb * R16;
+        if (cb < rb) continue;  // symmetric: upper tiles only
+        const double* pa = row_ptr(rb * 16 + r);
+        const double* pb = row_ptr(cb * 16 + r);
+        f64x4 acc = {0., 0., 0., 0.};
+        for (int kk = k0; kk < k1; kk += 16) {
+            const int px = kk + 4 * g;  // this lane's 4 consecutive pixels
+            double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (px + s < k1) {
+                    if (pa) a[s] = pa[px + s] * Qk[px + s];
+                    if (pb) b[s] = pb[px + s];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int ra = rb * 16 + g + 4 * reg, rc = cb * 16 + r;
+            if (ra >= nrows - 1 || rc >= nrows) continue;
+            const double val = acc[reg];
+            if (val == 0.0) continue;
+            const int ea = ra / 6, ca = ra - ea * 6;
+            const int ia = W.ent_pose[n0 + ea] * 6 + ca;
+            if (rc == nrows - 1) {
+                atomicAdd(&W.u[ia], val);
+            } else {
+                const int eb = rc / 6, cc = rc - eb * 6;
+                const int ibx = W.ent_pose[n0 + eb] * 6 + cc;
+                atomicAdd(&W.S[(size_t)ia * n6 + ibx], val);
+                if (rb != cb) atomicAdd(&W.S[(size_t)ibx * n6 + ia], val);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// solve: (H + (ep + lm*diag H) I - S) dx = v - u   in float64, one workgroup.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void dba_solve_kernel(int n, double lm, double ep, int use_schur,
+                                                         DbaWs W) {
+    extern __shared__ double lds[];
+    __shared__ int fail;
+    double* A = (n <= 128) ? lds : W.chol;
+    const int tid = threadIdx.x;
+    if (tid == 0) fail = 0;
+    for (int idx = tid; idx < n * n; idx += 1024) {
+        const int i = idx / n, j = idx - i * n;
+        double a = W.H[idx];
+        if (i == j) a += ep + lm * a;
+        if (use_schur) a -= W.S[idx];
+        A[idx] = a;
+    }
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        const double djj = A[j * n + j];
+        if (!(djj > 0.0)) { if (tid == 0) fail = 1; }
+        __syncthreads();
+        if (fail) break;
+        const double inv = 1.0 / sqrt(djj);
+        __syncthreads();
+        for (int i = j + tid; i < n; i += 1024) A[i * n + j] *= inv;   // column j (incl. diagonal)
+        __syncthreads();
+        const int m = n - j - 1;
+        for (int idx = tid; idx < m * m; idx += 1024) {
+            const int a = j + 1 + idx / m, b = j + 1 + idx % m;
+            if (b <= a) A[a * n + b] -= A[a * n + j] * A[b * n + j];
+        }
+        __syncthreads();
+    }
+    if (fail) {  // chol.py:9-17: a failed factorisation yields a zero update
+        for (int i = tid; i < n; i += 1024) W.dx[i] = 0.0;
+        if (tid == 0) W.status[1] = 1;
+        return;
+    }
+    // forward / backward substitution with the lower factor (serial over rows)
+    double* y = W.dx;
+    for (int i = tid; i < n; i += 1024) y[i] = W.v[i] - (use_schur ? W.u[i] : 0.0);
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        if (tid == 0) y[j] /= A[j * n + j];
+        __syncthreads();
+        const double yj = y[j];
+        for (int i = j + 1 + tid; i < n; i += 1024) y[i] -= A[i * n + j] * yj;
+        __syncthreads();
+    }
+    for (int j = n - 1; j >= 0; --j) {
+        if (tid == 0) y[j] /= A[j * n + j];
+        __syncthreads();
+        const double yj = y[j];
+        for (int i = tid; i < j; i += 1024) y[i] -= A[j * n + i] * yj;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// retraction
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dba_disp_retract_kernel(float* __restrict__ disps, int HW,
+                                                               DbaWs W) {
+    const int k = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW || W.status[2]) return;
+    const int n0 = W.ent_start[k], n1 = W.ent_start[k + 1];
+    double acc = 0.;
+    for (int n = n0; n < n1; ++n) {
+        const double* Er = W.E + (size_t)W.ent_row[n] * 6 * HW + p;
+        const double* dxp = W.dx + W.ent_pose[n] * 6;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) acc += Er[(size_t)m * HW] * dxp[m];
+    }
+    const size_t o = (size_t)k * HW + p;
+    const double dzv = W.Q[o] * (W.w[o] - acc);
+    float* dp = disps + (size_t)W.kx[k] * HW + p;
+    double nd = (double)*dp + dzv;
+    nd = nd > 10. ? 0. : nd;          // ba.py:101-102
+    *dp = (float)fmax(nd, 0.);
+}
+
+__global__ void dba_pose_retract_kernel(float* __restrict__ poses, int t0, int P, DbaWs W) {
+    const int pidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pidx >= P || W.status[2]) return;
+    const double* xi = W.dx + 6 * pidx;
+    const double tau[3] = {xi[0], xi[1], xi[2]}, phi[3] = {xi[3], xi[4], xi[5]};
+    const double th2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
+    const double th = sqrt(th2);
+    double a, b, c;
+    if (th < 1e-8) { a = 0.5 - th2 / 48.0; b = 0.5 - th2 / 24.0; c = 1.0 / 6 - th2 / 120.0; }
+    else { a = sin(0.5 * th) / th; b = (1 - cos(th)) / th2; c = (th - sin(th)) / (th2 * th); }
+    const double qe[4] = {a * phi[0], a * phi[1], a * phi[2], cos(0.5 * th)};
+    // V tau = tau + b phi x tau + c phi x (phi x tau)
+    const double pt[3] = {phi[1] * tau[2] - phi[2] * tau[1], phi[2] * tau[0] - phi[0] * tau[2],
+                          phi[0] * tau[1] - phi[1] * tau[0]};
+    const double ppt[3] = {phi[1] * pt[2] - phi[2] * pt[1], phi[2] * pt[0] - phi[0] * pt[2],
+                           phi[0] * pt[1] - phi[1] * pt[0]};
+    const double te[3] = {tau[0] + b * pt[0] + c * ppt[0], tau[1] + b * pt[1] + c * ppt[1],
+                          tau[2] + b * pt[2] + c * ppt[2]};
+    float* ps = poses + 7 * (t0 + pidx);
+    const double t[3] = {ps[0], ps[1], ps[2]}, q[4] = {ps[3], ps[4], ps[5], ps[6]};
+    double rt[3], qn[4];
+    qrot(qe, t, rt);
+    qmul(qe, q, qn);
+    const double nrm = 1.0 / sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+    ps[0] = (float)(rt[0] + te[0]); ps[1] = (float)(rt[1] + te[1]); ps[2] = (float)(rt[2] + te[2]);
+    ps[3] = (float)(qn[0] * nrm); ps[4] = (float)(qn[1] * nrm); ps[5] = (float)(qn[2] * nrm);
+    ps[6] = (float)(qn[3] * nrm);
+}
+
+__global__ void dba_reduced_kernel(int n, DbaWs W, double* __restrict__ Hout,
+                                   double* __restrict__ vout) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n * n) Hout[idx] = W.H[idx] - W.S[idx];
+    if (idx < n) vout[idx] = W.v[idx] - W.u[idx];
+}
+
+// float32 copies of Q and E for the depth-covariance consumer; rows of E that
+// belong to fixed poses / fixed targets were never written and export as zero.
+__global__ void dba_export_kernel(int HW, int P, int E, int M, int t0, int t1, DbaWs W,
+                                  float* __restrict__ Qout, float* __restrict__ Eout) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nq = (size_t)M * HW, ne = (size_t)(P + E) * 6 * HW;
+    if (idx < nq) Qout[idx] = (float)W.Q[idx];
+    if (idx < ne) {
+        const int row = (int)(idx / ((size_t)6 * HW));
+        bool live;
+        if (row < P) {
+            live = false;
+            for (int k = 0; k < M; ++k) live |= (W.kx[k] == row + t0);
+        } else {
+            const int j = W.jp[row - P];
+            live = j >= t0 && j < t1;
+        }
+        Eout[idx] = live ? (float)W.E[idx] : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host-side stages
+// ---------------------------------------------------------------------------
+struct DbaDims { int B, ht, wd, E, M, t0, t1; };
+
+static int check_dims(const DbaDims& d) {
+    VINGS_REQUIRE(d.B > 0 && d.B <= kMaxFrames, "1 <= frames <= 4096");
+    VINGS_REQUIRE(d.ht > 0 && d.wd > 0 && d.E >= 0 && d.M >= 0, "sizes");
+    VINGS_REQUIRE(d.t0 >= 0 && d.t1 >= d.t0 && d.t1 <= d.B, "0 <= t0 <= t1 <= frames");
+    return VINGS_OK;
+}
+
+static int stage_linearize(const float* poses, const float* disps, const float* intr,
+                           const float* disps_sens, const float* target, const float* weight,
+                           const float* eta, const int64_t* ii, const int64_t* jj,
+                           const DbaDims& d, int motion_only, const DbaWs& W, hipStream_t s) {
+    const int P = d.t1 - d.t0, HW = d.ht * d.wd;
+    const size_t n = 6 * (size_t)P;
+    ProfScope prof(PROF_DBA_JAC, s);
+    VINGS_CHECK_HIP(hipMemsetAsync(W.H, 0, sizeof(double) * n * n, s));
+    VINGS_CHECK_HIP(hipMemsetAsync(W.v, 0, sizeof(double) * n, s));
+    dba_index_kernel<<<1, 256, 0, s>>>(ii, jj, d.B, d.E, d.M, d.t0, d.t1, W);
+    VINGS_LAUNCH_CHECK();
+    if (d.M > 0 && d.E > 0) {
+        dim3 grid(cdiv(HW, 256), d.M);
+        dba_linearize_kernel<<<grid, 256, 0, s>>>(poses, disps, intr, disps_sens, target, weight,
+                                                  eta, d.ht, d.wd, d.E, d.M, d.t0, d.t1,
+                                                  motion_only, W);
+        VINGS_LAUNCH_CHECK();
+    }
+    return VINGS_OK;
+}
+
+static int stage_schur(const DbaDims& d, const DbaWs& W, hipStream_t s) {
+    const int P = d.t1 - d.t0, HW = d.ht * d.wd;
+    const size_t n = 6 * (size_t)P;
+    ProfScope prof(PROF_DBA_SCHUR, s);
+    VINGS_CHECK_HIP(hipMemsetAsync(W.S, 0, sizeof(double) * n * n, s));
+    VINGS_CHECK_HIP(hipMemsetAsync(W.u, 0, sizeof(double) * n, s));
+    if (d.M > 0 && P > 0) {
+        dim3 grid(cdiv(HW, kSchurSlice), d.M);
+        dba_schur_kernel<<<grid, 256, 0, s>>>(HW, P, W);
+        VINGS_LAUNCH_CHECK();
+    }
+    return VINGS_OK;
+}
+
+static int stage_solve(const DbaDims& d, float lm, float ep, int motion_only, const DbaWs& W,
+                       hipStream_t s) {
+    const int n = 6 * (d.t1 - d.t0);
+    if (n == 0) return VINGS_OK;
+    ProfScope prof(PROF_DBA_SOLVE, s);
+    const size_t lds = n <= 128 ? sizeof(double) * (size_t)n * n : 0;
+    if (lds > 48 * 1024)
+        VINGS_CHECK_HIP(hipFuncSetAttribute((const void*)dba_solve_kernel,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dba_solve_kernel<<<1, 1024, lds, s>>>(n, (double)lm, (double)ep, motion_only ? 0 : 1, W);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}
+
+static int stage_retract(float* poses, float* disps, const DbaDims& d, int motion_only,
+                         const DbaWs& W, hipStream_t s) {
+    const int P = d.t1 - d.t0, HW = d.ht * d.wd;
+    ProfScope prof(PROF_DBA_RETRACT, s);
+    if (!motion_only && d.M > 0) {
+        dim3 grid(cdiv(HW, 256), d.M);
+        dba_disp_retract_kernel<<<grid, 256, 0, s>>>(disps, HW, W);
+        VINGS_LAUNCH_CHECK();
+    }
+    if (P > 0) {
+        dba_pose_retract_kernel<<<cdiv(P, 64), 64, 0, s>>>(poses, d.t0, P, W);
+        VINGS_LAUNCH_CHECK();
+    }
+    return VINGS_OK;
+}
+
+}  // namespace vings
+
+using namespace vings;
+
+extern "C" int vings_dba_layout_query(int ht, int wd, int E, int P, int M, vings_dba_layout* out) {
+    VINGS_REQUIRE(out && ht > 0 && wd > 0 && E >= 0 && P >= 0 && M >= 0, "layout args");
+    layout(ht, wd, E, P, M, out);
+    return VINGS_OK;
+}
+
+#define DBA_COMMON_CHECKS()                                                                   \
+    const DbaDims dims{B, ht, wd, E, M, t0, t1};                                              \
+    { int rc_ = check_dims(dims); if (rc_ != VINGS_OK) return rc_; }                         \
+    VINGS_REQUIRE(workspace && ((uintptr_t)workspace & 255) == 0, "workspace 256-byte aligned"); \
+    vings_dba_layout L;                                                                       \
+    layout(ht, wd, E, t1 - t0, M, &L);                                                        \
+    if (workspace_bytes < L.total_bytes) {                                                    \
+        set_error("dba workspace too small: %zu < %zu", workspace_bytes, L.total_bytes);      \
+        return VINGS_ERR_CAPACITY;                                                            \
+    }                                                                                         \
+    const DbaWs W = carve(workspace, L);                                                      \
+    hipStream_t s = (hipStream_t)stream;
+
+extern "C" int vings_dba_linearize(const float* poses, const float* disps, const float* intr,
+                                   const float* disps_sens, const float* target,
+                                   const float* weight, const float* eta, const int64_t* ii,
+                                   const int64_t* jj, int B, int ht, int wd, int E, int M, int t0,
+                                   int t1, int motion_only, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    DBA_COMMON_CHECKS();
+    VINGS_REQUIRE(poses && disps && intr && (E == 0 || (target && weight && ii && jj)) &&
+                      (motion_only || M == 0 || eta),
+                  "null pointer");
+    int rc = stage_linearize(poses, disps, intr, disps_sens, target, weight, eta, ii, jj, dims,
+                             motion_only, W, s);
+    if (rc != VINGS_OK) return rc;
+    if (!motion_only) rc = stage_schur(dims, W, s);
+    return rc;
+}
+
+extern "C" int vings_dba_reduced_system(int B, int ht, int wd, int E, int M, int t0, int t1,
+                                        void* workspace, size_t workspace_bytes, double* H_out,
+                                        double* v_out, void* stream) {
+    DBA_COMMON_CHECKS();
+    VINGS_REQUIRE(H_out && v_out, "null pointer");
+    const int n = 6 * (t1 - t0);
+    if (n == 0) return VINGS_OK;
+    dba_reduced_kernel<<<cdiv((int64_t)n * n, 256), 256, 0, s>>>(n, W, H_out, v_out);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}
+
+extern "C" int vings_dba_export(int B, int ht, int wd, int E, int M, int t0, int t1,
+                                void* workspace, size_t workspace_bytes, float* Q_out,
+                                float* E_out, void* stream) {
+    DBA_COMMON_CHECKS();
+    VINGS_REQUIRE(Q_out && E_out, "null pointer");
+    const int HW = ht * wd, P = t1 - t0;
+    const size_t n = (size_t)(P + E) * 6 * HW;
+    const size_t nq = (size_t)M * HW;
+    const size_t total = n > nq ? n : nq;
+    if (total == 0) return VINGS_OK;
+    dba_export_kernel<<<cdiv((int64_t)total, 256), 256, 0, s>>>(HW, P, E, M, t0, t1, W, Q_out, E_out);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}
+
+extern "C" int vings_dba_retract(float* poses, float* disps, const double* dx, int B, int ht,
+                                 int wd, int E, int M, int t0, int t1, int motion_only,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    DBA_COMMON_CHECKS();
+    VINGS_REQUIRE(poses && disps, "null pointer");
+    if (dx)
+        VINGS_CHECK_HIP(hipMemcpyAsync(W.dx, dx, sizeof(double) * 6 * (size_t)(t1 - t0),
+                                       hipMemcpyDeviceToDevice, s));
+    return stage_retract(poses, disps, dims, motion_only, W, s);
+}
+
+extern "C" int vings_dba_ba(float* poses, float* disps, const float* intr,
+                            const float* disps_sens, const float* target, const float* weight,
+                            const float* eta, const int64_t* ii, const int64_t* jj, int B, int ht,
+                            int wd, int E, int M, int t0, int t1, int itrs, float lm, float ep,
+                            int motion_only, void* workspace, size_t workspace_bytes,
+                            void* stream) {
+    DBA_COMMON_CHECKS();
+    VINGS_REQUIRE(poses && disps && intr && (E == 0 || (target && weight && ii && jj)) &&
+                      (motion_only || M == 0 || eta),
+                  "null pointer");
+    if (E == 0 || t1 == t0) return VINGS_OK;
+    for (int it = 0; it < itrs; ++it) {
+        int rc = stage_linearize(poses, disps, intr, disps_sens, target, weight, eta, ii, jj, dims,
+                                 motion_only, W, s);
+        if (rc != VINGS_OK) return rc;
+        if (!motion_only) { rc = stage_schur(dims, W, s); if (rc != VINGS_OK) return rc; }
+        rc = stage_solve(dims, lm, ep, motion_only, W, s);
+        if (rc != VINGS_OK) return rc;
+        rc = stage_retract(poses, disps, dims, motion_only, W, s);
+        if (rc != VINGS_OK) return rc;
+    }
+    return VINGS_OK;
+}

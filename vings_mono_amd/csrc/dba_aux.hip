@@ -1,0 +1,209 @@
+// Tracker-side helpers of the dense-BA path on gfx950: frame distance and the
+// correlation-volume window lookup (forward and backward).
+//
+// Serves droid_backends.frame_distance
+// (/root/reference/scripts/frontend/depth_video.py:289-299) and
+// droid_backends.corr_index_forward/backward
+// (/root/reference/scripts/frontend/modules/corr.py:12,19,40-50).
+#include <hip/hip_fp16.h>
+
+#include "common.hpp"
+
+namespace vings {
+
+constexpr float kMinDepthAux = 0.2f;
+
+__device__ __forceinline__ void qrotf(const float* q, const float* v, float* o) {
+    const float x = q[0], y = q[1], z = q[2], w = q[3];
+    const float tx = 2 * (y * v[2] - z * v[1]), ty = 2 * (z * v[0] - x * v[2]), tz = 2 * (x * v[1] - y * v[0]);
+    o[0] = v[0] + w * tx + (y * tz - z * ty);
+    o[1] = v[1] + w * ty + (z * tx - x * tz);
+    o[2] = v[2] + w * tz + (x * ty - y * tx);
+}
+
+// One workgroup per candidate edge; lanes stride over the pixel grid.
+__global__ __launch_bounds__(256) void frame_distance_kernel(
+    const float* __restrict__ poses, const float* __restrict__ disps,
+    const float* __restrict__ intr, const int64_t* __restrict__ ii,
+    const int64_t* __restrict__ jj, int B, int ht, int wd, float beta, float* __restrict__ out) {
+    __shared__ float snum[4], sden[4];
+    const int e = blockIdx.x;
+    const long i = ii[e], j = jj[e];
+    const int HW = ht * wd;
+    if (i < 0 || i >= B || j < 0 || j >= B) { if (threadIdx.x == 0) out[e] = 1000.f; return; }
+    float t[3], q[4];
+    if (i == j) {
+        t[0] = -0.1f; t[1] = t[2] = 0.f; q[0] = q[1] = q[2] = 0.f; q[3] = 1.f;
+    } else {
+        const float* pi = poses + 7 * i;
+        const float* pj = poses + 7 * j;
+        const float a[4] = {pj[3], pj[4], pj[5], pj[6]};
+        const float b[4] = {-pi[3], -pi[4], -pi[5], pi[6]};
+        q[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+        q[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+        q[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+        q[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+        float rt[3];
+        const float ti[3] = {pi[0], pi[1], pi[2]};
+        qrotf(q, ti, rt);
+        t[0] = pj[0] - rt[0]; t[1] = pj[1] - rt[1]; t[2] = pj[2] - rt[2];
+    }
+    const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+    float num = 0.f, den = 0.f;
+    for (int p = threadIdx.x; p < HW; p += 256) {
+        const int u = p % wd, v = p / wd;
+        const float d = disps[(size_t)i * HW + p];
+        const float X0[3] = {((float)u - cx) / fx, ((float)v - cy) / fy, 1.f};
+        float X1[3];
+        qrotf(q, X0, X1);
+        X1[0] += t[0] * d; X1[1] += t[1] * d; X1[2] += t[2] * d;
+        if (X1[2] > kMinDepthAux) {
+            const float du = fx * X1[0] / X1[2] + cx - (float)u, dv = fy * X1[1] / X1[2] + cy - (float)v;
+            num += beta * sqrtf(du * du + dv * dv);
+            den += beta;
+        }
+        const float Y[3] = {X0[0] + t[0] * d, X0[1] + t[1] * d, X0[2] + t[2] * d};
+        if (Y[2] > kMinDepthAux) {
+            const float du = fx * Y[0] / Y[2] + cx - (float)u, dv = fy * Y[1] / Y[2] + cy - (float)v;
+            num += (1.f - beta) * sqrtf(du * du + dv * dv);
+            den += (1.f - beta);
+        }
+    }
+    num = wave_sum(num);
+    den = wave_sum(den);
+    if ((threadIdx.x & 63) == 0) { snum[threadIdx.x >> 6] = num; sden[threadIdx.x >> 6] = den; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float n = snum[0] + snum[1] + snum[2] + snum[3];
+        const float dd = sden[0] + sden[1] + sden[2] + sden[3];
+        out[e] = (dd / (float)HW < 0.75f) ? 1000.f : n / dd;
+    }
+}
+
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(__half v) { return __half2float(v); }
+__device__ __forceinline__ void from_f(float& o, float v) { o = v; }
+__device__ __forceinline__ void from_f(__half& o, float v) { o = __float2half(v); }
+
+// One lane per source pixel (e,y,x): it owns the h2 x w2 slice volume[e,y,x].
+template <typename T>
+__global__ __launch_bounds__(256) void corr_index_fwd_kernel(
+    const T* __restrict__ volume, const float* __restrict__ coords, T* __restrict__ corr, int E,
+    int h1, int w1, int h2, int w2, int r) {
+    const int64_t n = (int64_t)E * h1 * w1;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int x = (int)(idx % w1), y = (int)((idx / w1) % h1), e = (int)(idx / ((int64_t)w1 * h1));
+    const size_t plane = (size_t)h1 * w1;
+    const float cxv = coords[((size_t)e * 2 + 0) * plane + (size_t)y * w1 + x];
+    const float cyv = coords[((size_t)e * 2 + 1) * plane + (size_t)y * w1 + x];
+    const float fx0 = floorf(cxv), fy0 = floorf(cyv);
+    const float dx = cxv - fx0, dy = cyv - fy0;
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const T* slice = volume + (size_t)idx * h2 * w2;
+    const int rd = 2 * r + 1;
+    auto fetch = [&](int yi, int xi) -> float {
+        return (yi >= 0 && yi < h2 && xi >= 0 && xi < w2) ? to_f(slice[(size_t)yi * w2 + xi]) : 0.f;
+    };
+    for (int i = 0; i < rd; ++i) {
+        const int yi = y0 + i - r;
+        float left0 = fetch(yi, x0 - r), left1 = fetch(yi + 1, x0 - r);
+        for (int j = 0; j < rd; ++j) {
+            const int xi = x0 + j - r;
+            const float right0 = fetch(yi, xi + 1), right1 = fetch(yi + 1, xi + 1);
+            const float v = (1.f - dx) * (1.f - dy) * left0 + dx * (1.f - dy) * right0 +
+                            (1.f - dx) * dy * left1 + dx * dy * right1;
+            from_f(corr[(((size_t)e * rd + i) * rd + j) * plane + (size_t)y * w1 + x], v);
+            left0 = right0; left1 = right1;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void corr_index_bwd_kernel(
+    const float* __restrict__ coords, const T* __restrict__ corr_grad, T* __restrict__ volume_grad,
+    int E, int h1, int w1, int h2, int w2, int r) {
+    const int64_t n = (int64_t)E * h1 * w1;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int x = (int)(idx % w1), y = (int)((idx / w1) % h1), e = (int)(idx / ((int64_t)w1 * h1));
+    const size_t plane = (size_t)h1 * w1;
+    const float cxv = coords[((size_t)e * 2 + 0) * plane + (size_t)y * w1 + x];
+    const float cyv = coords[((size_t)e * 2 + 1) * plane + (size_t)y * w1 + x];
+    const float fx0 = floorf(cxv), fy0 = floorf(cyv);
+    const float dx = cxv - fx0, dy = cyv - fy0;
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    T* slice = volume_grad + (size_t)idx * h2 * w2;
+    const int rd = 2 * r + 1;
+    auto push = [&](int yi, int xi, float v) {
+        if (yi >= 0 && yi < h2 && xi >= 0 && xi < w2) {
+            T& dst = slice[(size_t)yi * w2 + xi];
+            from_f(dst, to_f(dst) + v);
+        }
+    };
+    for (int i = 0; i < rd; ++i)
+        for (int j = 0; j < rd; ++j) {
+            const float g = to_f(corr_grad[(((size_t)e * rd + i) * rd + j) * plane + (size_t)y * w1 + x]);
+            const int yi = y0 + i - r, xi = x0 + j - r;
+            push(yi, xi, (1.f - dx) * (1.f - dy) * g);
+            push(yi, xi + 1, dx * (1.f - dy) * g);
+            push(yi + 1, xi, (1.f - dx) * dy * g);
+            push(yi + 1, xi + 1, dx * dy * g);
+        }
+}
+
+}  // namespace vings
+
+using namespace vings;
+
+extern "C" int vings_frame_distance(const float* poses, const float* disps, const float* intr,
+                                    const int64_t* ii, const int64_t* jj, int B, int ht, int wd,
+                                    int E, float beta, float* out, void* stream) {
+    VINGS_REQUIRE(B > 0 && ht > 0 && wd > 0 && E >= 0, "sizes");
+    if (E == 0) return VINGS_OK;
+    VINGS_REQUIRE(poses && disps && intr && ii && jj && out, "null pointer");
+    ProfScope prof(PROF_AUX, (hipStream_t)stream);
+    frame_distance_kernel<<<E, 256, 0, (hipStream_t)stream>>>(poses, disps, intr, ii, jj, B, ht, wd,
+                                                              beta, out);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}
+
+extern "C" int vings_corr_index_forward(const void* volume, const float* coords, void* corr, int E,
+                                        int h1, int w1, int h2, int w2, int r, int half,
+                                        void* stream) {
+    VINGS_REQUIRE(E >= 0 && h1 > 0 && w1 > 0 && h2 > 0 && w2 > 0 && r >= 0, "sizes");
+    if (E == 0) return VINGS_OK;
+    VINGS_REQUIRE(volume && coords && corr, "null pointer");
+    const int64_t n = (int64_t)E * h1 * w1;
+    ProfScope prof(PROF_AUX, (hipStream_t)stream);
+    if (half)
+        corr_index_fwd_kernel<__half><<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(
+            (const __half*)volume, coords, (__half*)corr, E, h1, w1, h2, w2, r);
+    else
+        corr_index_fwd_kernel<float><<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(
+            (const float*)volume, coords, (float*)corr, E, h1, w1, h2, w2, r);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}
+
+extern "C" int vings_corr_index_backward(const float* coords, const void* corr_grad,
+                                         void* volume_grad, int E, int h1, int w1, int h2, int w2,
+                                         int r, int half, void* stream) {
+    VINGS_REQUIRE(E >= 0 && h1 > 0 && w1 > 0 && h2 > 0 && w2 > 0 && r >= 0, "sizes");
+    if (E == 0) return VINGS_OK;
+    VINGS_REQUIRE(coords && corr_grad && volume_grad, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)E * h1 * w1;
+    const size_t bytes = (size_t)n * h2 * w2 * (half ? 2 : 4);
+    VINGS_CHECK_HIP(hipMemsetAsync(volume_grad, 0, bytes, s));
+    ProfScope prof(PROF_AUX, s);
+    if (half)
+        corr_index_bwd_kernel<__half><<<cdiv(n, 256), 256, 0, s>>>(
+            coords, (const __half*)corr_grad, (__half*)volume_grad, E, h1, w1, h2, w2, r);
+    else
+        corr_index_bwd_kernel<float><<<cdiv(n, 256), 256, 0, s>>>(
+            coords, (const float*)corr_grad, (float*)volume_grad, E, h1, w1, h2, w2, r);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}
