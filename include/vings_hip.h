@@ -42,7 +42,8 @@ const char* vings_last_error(void);
 /* ABI version; bumped when a signature changes. */
 int vings_abi_version(void);
 
-#define VINGS_GEOM_STRIDE 20 /* floats per packed splat record */
+#define VINGS_GEOM_STRIDE 24 /* floats per packed splat record (96 B, 16-byte aligned rows) */
+#define VINGS_GRAD_STRIDE 20 /* floats per packed splat gradient record */
 #define VINGS_AUX_CHANNELS 9 /* allmap channels */
 #define VINGS_TILE 16
 
@@ -54,7 +55,9 @@ int vings_abi_version(void);
  * in : means3D[N,3] scales[N,2] rotations[N,4](w,x,y,z) opacities[N]
  *      colors[N,3] flow[N,2] or NULL; viewmatrix[16] projmatrix[16] as the
  *      flat storage of the reference's transposed matrices (cameras.py:58-60)
- * out: geom[N,20]  packed record {T[9], xy[2], normal[3], opacity, rgb[3], flow[2]}
+ * out: geom[N,24]  packed record {T[9], xy[2], normal[3], opacity, rgb[3], flow[2],
+ *                  box[4] = xmin,xmax,ymin,ymax of the pixels the splat can reach with
+ *                  alpha >= 1/255 (conservative; lets a wave skip the splat)}
  *                  (rows of culled splats are left untouched)
  *      depth[N] radii[N](int32) rect[N,4](int32 x0,y0,x1,y1 in tiles)
  *      tiles_touched[N](uint32)

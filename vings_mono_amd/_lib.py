@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvings_hip.so")
+# VINGS_HIP_LIB points at an alternative build of the same library (kernel A/B experiments)
+LIB_PATH = os.environ.get("VINGS_HIP_LIB") or os.path.join(_HERE, "libvings_hip.so")
 
 _c = ctypes
 _P = _c.c_void_p

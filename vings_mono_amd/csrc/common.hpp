@@ -73,6 +73,26 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// a + b after v_permlane32_swap: lanes 0-31 receive a[l] + a[l+32], lanes 32-63
+// receive b[l-32] + b[l].  The two results of the swap builtin pass through an empty
+// asm because hipcc (ROCm 7.2) otherwise folds r[0] + r[1] into 2 * r[0].
+__device__ __forceinline__ float swap32_add(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a),
+                                                    __builtin_bit_cast(unsigned, b), false, false);
+    unsigned r0 = r[0], r1 = r[1];
+    asm volatile("" : "+v"(r0), "+v"(r1));
+    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+}
+// a + b after v_permlane16_swap: even 16-lane rows receive a[row] + a[row+1], odd rows
+// receive b[row-1] + b[row].
+__device__ __forceinline__ float swap16_add(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a),
+                                                    __builtin_bit_cast(unsigned, b), false, false);
+    unsigned r0 = r[0], r1 = r[1];
+    asm volatile("" : "+v"(r0), "+v"(r1));
+    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+}
+
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);

@@ -2,14 +2,18 @@
 //
 // One 256-lane workgroup (4 wave64) per 16x16 pixel tile, one lane per pixel;
 // each wave covers a 16x4 pixel strip.  The tile's sorted splat list is
-// streamed through LDS in batches of 256 packed 80-byte records
-// (one gather per lane, then every lane reads the same record: LDS
-// broadcast, no bank conflicts).
+// streamed through LDS in batches of 256 packed 96-byte records (one gather
+// per lane).  While staging, every lane tests its splat's alpha >= 1/255 pixel
+// box against the four strips of the tile and the waves publish one 64-bit
+// ballot per (loader wave, strip).  A render wave then walks only the set bits
+// of its own four ballots with scalar bit scans, so splats that cannot reach
+// the strip cost nothing, and reads each surviving record as an LDS broadcast
+// (every lane the same address: no bank conflicts), one record ahead of use.
 //
-// Backward walks the same list back to front.  Per splat the 20 partial
-// gradients of the contributing pixels are summed across the wave, the four
-// waves combine in an LDS accumulator for the batch, and each batch is
-// flushed with one global float atomic per (splat, component).
+// Backward walks the same bits back to front.  Per splat the 20 partial
+// gradients of the contributing pixels are summed over each 16-lane DPP row,
+// the rows of the four waves meet in an LDS accumulator for the batch, and each
+// batch is flushed with one global float atomic per (splat, component).
 //
 // Serves GaussianRasterizer.forward / backward as called at
 // /root/reference/scripts/gaussian/gaussian_base.py:193-203,382 and consumed
@@ -26,6 +30,10 @@ constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kTMin = 0.0001f;
 constexpr int kBatch = 256;
 constexpr int kRec4 = VINGS_GEOM_STRIDE / 4;  // float4 per record
+constexpr int kGrad = VINGS_GRAD_STRIDE;      // gradient components per splat
+#ifndef VINGS_ABLATE
+#define VINGS_ABLATE 0
+#endif
 
 struct Splat {  // unpacked view of one record
     float Tu[3], Tv[3], Tw[3];
@@ -36,17 +44,24 @@ struct Splat {  // unpacked view of one record
     float fl[2];
 };
 
-__device__ __forceinline__ Splat unpack(const float4* __restrict__ r) {
-    const float4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4];
+struct Rec5 { float4 a, b, c, d, e; };  // the five float4 of a record the blend needs
+
+__device__ __forceinline__ Rec5 load_rec(const float4* __restrict__ r) {
+    Rec5 q;
+    q.a = r[0]; q.b = r[1]; q.c = r[2]; q.d = r[3]; q.e = r[4];
+    return q;
+}
+
+__device__ __forceinline__ Splat unpack(const Rec5& q) {
     Splat s;
-    s.Tu[0] = a.x; s.Tu[1] = a.y; s.Tu[2] = a.z;
-    s.Tv[0] = a.w; s.Tv[1] = b.x; s.Tv[2] = b.y;
-    s.Tw[0] = b.z; s.Tw[1] = b.w; s.Tw[2] = c.x;
-    s.cx = c.y; s.cy = c.z;
-    s.n[0] = c.w; s.n[1] = d.x; s.n[2] = d.y;
-    s.opa = d.z;
-    s.rgb[0] = d.w; s.rgb[1] = e.x; s.rgb[2] = e.y;
-    s.fl[0] = e.z; s.fl[1] = e.w;
+    s.Tu[0] = q.a.x; s.Tu[1] = q.a.y; s.Tu[2] = q.a.z;
+    s.Tv[0] = q.a.w; s.Tv[1] = q.b.x; s.Tv[2] = q.b.y;
+    s.Tw[0] = q.b.z; s.Tw[1] = q.b.w; s.Tw[2] = q.c.x;
+    s.cx = q.c.y; s.cy = q.c.z;
+    s.n[0] = q.c.w; s.n[1] = q.d.x; s.n[2] = q.d.y;
+    s.opa = q.d.z;
+    s.rgb[0] = q.d.w; s.rgb[1] = q.e.x; s.rgb[2] = q.e.y;
+    s.fl[0] = q.e.z; s.fl[1] = q.e.w;
     return s;
 }
 
@@ -77,24 +92,84 @@ __device__ __forceinline__ bool eval_hit(const Splat& s, float fx, float fy, Hit
     return h.alpha >= kAlphaMin;
 }
 
-__device__ __forceinline__ void stage_batch(float4* __restrict__ lds, const float* __restrict__ geom,
+// Gather this lane's record of the batch into LDS and publish, per strip of the
+// tile, the ballot of lanes whose splat can reach that strip.
+__device__ __forceinline__ void stage_batch(float4* __restrict__ lds,
+                                            unsigned long long* __restrict__ hit,
+                                            const float* __restrict__ geom,
                                             const uint32_t* __restrict__ vals, uint32_t idx,
-                                            uint32_t end, uint32_t* __restrict__ ids) {
+                                            uint32_t end, uint32_t* __restrict__ ids, float tx0,
+                                            float ty0) {
+    uint32_t mask = 0;
     if (idx < end) {
         const uint32_t id = vals[idx];
         if (ids) ids[threadIdx.x] = id;
         const float4* src = reinterpret_cast<const float4*>(geom + (size_t)id * VINGS_GEOM_STRIDE);
+        float4 r[kRec4];
 #pragma unroll
-        for (int k = 0; k < kRec4; ++k) lds[threadIdx.x * kRec4 + k] = src[k];
+        for (int k = 0; k < kRec4; ++k) r[k] = src[k];
+#pragma unroll
+        for (int k = 0; k < kRec4 - 1; ++k) lds[threadIdx.x * (kRec4 - 1) + k] = r[k];
+        const float4 bx = r[kRec4 - 1];  // xmin, xmax, ymin, ymax
+        if (!(bx.x > tx0 + 15.f || bx.y < tx0)) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (!(bx.z > ty0 + 4.f * s + 3.f || bx.w < ty0 + 4.f * s)) mask |= 1u << s;
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const unsigned long long b = __ballot((mask >> s) & 1u);
+        if (lane == 0) hit[wv * 4 + s] = b;
     }
 }
+
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Scalar walk over the set bits of a wave's four ballots.
+struct HitWalk {
+    const unsigned long long* hit;
+    int strip, lw;
+    unsigned long long m;
+    __device__ __forceinline__ void begin_forward(const unsigned long long* h, int s) {
+        hit = h; strip = s; lw = 0; m = uniform_u64(h[s]);
+    }
+    __device__ __forceinline__ bool next_forward(int& j) {
+        while (m == 0ull) {
+            if (++lw > 3) return false;
+            m = uniform_u64(hit[lw * 4 + strip]);
+        }
+        j = lw * 64 + __builtin_ctzll(m);
+        m &= m - 1ull;
+        return true;
+    }
+    __device__ __forceinline__ void begin_backward(const unsigned long long* h, int s) {
+        hit = h; strip = s; lw = 3; m = uniform_u64(h[12 + s]);
+    }
+    __device__ __forceinline__ bool next_backward(int& j) {
+        while (m == 0ull) {
+            if (--lw < 0) return false;
+            m = uniform_u64(hit[lw * 4 + strip]);
+        }
+        const int bit = 63 - __builtin_clzll(m);
+        j = lw * 64 + bit;
+        m &= ~(1ull << bit);
+        return true;
+    }
+};
 
 __global__ __launch_bounds__(256) void blend_fwd_kernel(
     int H, int W, int gx, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ vals,
     const float* __restrict__ geom, const float* __restrict__ bg,
     const uint8_t* __restrict__ pixel_mask, float* __restrict__ out_color,
     float* __restrict__ allmap, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
-    __shared__ float4 rec[kBatch * kRec4];
+    __shared__ float4 rec[kBatch * (kRec4 - 1)];
+    __shared__ unsigned long long hit[16];
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
     const int px = tx * 16 + (threadIdx.x & 15), py = ty * 16 + (threadIdx.x >> 4);
@@ -105,37 +180,56 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(
     bool done = !inside || masked;
     const float fx = (float)px, fy = (float)py;
     const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+    const int wv = threadIdx.x >> 6;
 
     float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, F0 = 0, F1 = 0;
     float T = 1.f, Dd = 0, M1 = 0, M2 = 0, dist = 0, med = 0;
-    uint32_t contributor = 0, last = 0, medc = 0;
+    uint32_t last = 0, medc = 0;
     const float c1 = kFarN / (kFarN - kNearN);
 
     for (uint32_t base = r0; base < r1; base += kBatch) {
         if (__syncthreads_and(done)) break;
-        stage_batch(rec, geom, vals, base + threadIdx.x, r1, nullptr);
+        stage_batch(rec, hit, geom, vals, base + threadIdx.x, r1, nullptr, (float)(tx * 16),
+                    (float)(ty * 16));
         __syncthreads();
-        const int cnt = min((uint32_t)kBatch, r1 - base);
-        for (int j = 0; j < cnt && !done; ++j) {
-            ++contributor;
-            const Splat s = unpack(rec + j * kRec4);
-            Hit h;
-            if (!eval_hit(s, fx, fy, h)) continue;
-            const float test_T = T * (1.f - h.alpha);
-            if (test_T < kTMin) { done = true; continue; }
-            const float w = h.alpha * T;
-            const float A = 1.f - T;
-            const float m = c1 * (1.f - kNearN / h.depth);
-            dist += (m * m * A + M2 - 2.f * m * M1) * w;
-            Dd += h.depth * w;
-            M1 += m * w;
-            M2 += m * m * w;
-            if (T > 0.5f) { med = h.depth; medc = contributor; }
-            N0 += s.n[0] * w; N1 += s.n[1] * w; N2 += s.n[2] * w;
-            C0 += s.rgb[0] * w; C1 += s.rgb[1] * w; C2 += s.rgb[2] * w;
-            F0 += s.fl[0] * w; F1 += s.fl[1] * w;
-            T = test_T;
-            last = contributor;
+        HitWalk walk;
+        walk.begin_forward(hit, wv);
+        int j;
+        bool has = walk.next_forward(j);
+        Rec5 cur;
+        if (has) cur = load_rec(rec + j * (kRec4 - 1));
+        while (has) {
+            int jn;
+            const bool hasn = walk.next_forward(jn);
+            Rec5 nxt;
+            if (hasn) nxt = load_rec(rec + jn * (kRec4 - 1));  // one record ahead of use
+            if (__ballot(!done) == 0ull) break;  // every pixel of this wave has saturated
+            if (!done) {
+                const uint32_t contributor = (base - r0) + (uint32_t)j + 1u;  // 1-based position
+                const Splat s = unpack(cur);
+                Hit h;
+                if (eval_hit(s, fx, fy, h)) {
+                    const float test_T = T * (1.f - h.alpha);
+                    if (test_T < kTMin) {
+                        done = true;
+                    } else {
+                        const float w = h.alpha * T;
+                        const float A = 1.f - T;
+                        const float m = c1 * (1.f - kNearN / h.depth);
+                        dist += (m * m * A + M2 - 2.f * m * M1) * w;
+                        Dd += h.depth * w;
+                        M1 += m * w;
+                        M2 += m * m * w;
+                        if (T > 0.5f) { med = h.depth; medc = contributor; }
+                        N0 += s.n[0] * w; N1 += s.n[1] * w; N2 += s.n[2] * w;
+                        C0 += s.rgb[0] * w; C1 += s.rgb[1] * w; C2 += s.rgb[2] * w;
+                        F0 += s.fl[0] * w; F1 += s.fl[1] * w;
+                        T = test_T;
+                        last = contributor;
+                    }
+                }
+            }
+            cur = nxt; j = jn; has = hasn;
         }
     }
     if (!inside) return;
@@ -164,7 +258,16 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(
 // ---------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------
-constexpr int kGrad = VINGS_GEOM_STRIDE;  // 20 gradient components per splat
+
+// Sum over the 16 lanes of a DPP row (one pixel row of the wave's strip); every
+// lane of the row receives the total.
+__device__ __forceinline__ float row_sum(float v) {
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);  // row_half_mirror
+    v += dpp_f<0x140>(v);  // row_mirror
+    return v;
+}
 
 __global__ __launch_bounds__(256) void blend_bwd_kernel(
     int H, int W, int gx, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ vals,
@@ -172,9 +275,10 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
     const uint8_t* __restrict__ pixel_mask, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_dallmap, float* __restrict__ dgeom) {
-    __shared__ float4 rec[kBatch * kRec4];
+    __shared__ float4 rec[kBatch * (kRec4 - 1)];
     __shared__ float acc[kBatch * kGrad];
     __shared__ uint32_t ids[kBatch];
+    __shared__ unsigned long long hit[16];
     __shared__ uint32_t wmax[4];
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
@@ -228,17 +332,28 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
         const uint32_t bstart = (uint32_t)b * kBatch;
         const int cnt = (int)min((uint32_t)kBatch, maxlast - bstart);
         __syncthreads();  // previous batch fully flushed
-        stage_batch(rec, geom, vals, r0 + bstart + threadIdx.x, r0 + bstart + cnt, ids);
+        stage_batch(rec, hit, geom, vals, r0 + bstart + threadIdx.x, r0 + bstart + cnt, ids,
+                    (float)(tx * 16), (float)(ty * 16));
         for (int k = threadIdx.x; k < cnt * kGrad; k += 256) acc[k] = 0.f;
         __syncthreads();
-        for (int j = cnt - 1; j >= 0; --j) {
+        HitWalk walk;
+        walk.begin_backward(hit, wv);
+        int j;
+        bool has = walk.next_backward(j);
+        Rec5 cur;
+        if (has) cur = load_rec(rec + j * (kRec4 - 1));
+        while (has) {
+            int jn;
+            const bool hasn = walk.next_backward(jn);
+            Rec5 nxt;
+            if (hasn) nxt = load_rec(rec + jn * (kRec4 - 1));  // one record ahead of use
             const uint32_t pos = bstart + j;
             float g[kGrad];
 #pragma unroll
             for (int k = 0; k < kGrad; ++k) g[k] = 0.f;
             bool contrib = false;
             if (pos < last) {
-                const Splat s = unpack(rec + j * kRec4);
+                const Splat s = unpack(cur);
                 Hit h;
                 if (eval_hit(s, fx, fy, h)) {
                     contrib = true;
@@ -311,20 +426,50 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
                     }
                 }
             }
-            if (__ballot(contrib) == 0ull) continue;  // wave-uniform
+            if (__ballot(contrib) != 0ull) {  // wave-uniform
+                // sum over each 16-lane row (one pixel row of the strip) with DPP only, then
+                // one LDS float atomic per row: four rows of four waves meet in the accumulator
+                // Transposing reduction.  v_permlane32_swap exchanges the upper half of one
+                // register with the lower half of another, so swap + add sums a PAIR of
+                // components over lanes l / l+32 and leaves one component per half;
+                // v_permlane16_swap does the same for odd/even 16-lane rows.  After the two
+                // steps 20 components have become 5 registers whose four rows hold different
+                // components (row r, register k -> component 4k + {0,2,1,3}[r]), each already
+                // summed over the four rows; a DPP row sum finishes them.
+                float v10[kGrad / 2];
 #pragma unroll
-            for (int k = 0; k < kGrad; ++k) {
-                const float v = wave_sum(g[k]);
-                if (lane == 0) atomicAdd(&acc[j * kGrad + k], v);
+                for (int i = 0; i < kGrad / 2; ++i) v10[i] = swap32_add(g[2 * i], g[2 * i + 1]);
+                float u5[kGrad / 4];
+#pragma unroll
+                for (int k = 0; k < kGrad / 4; ++k)
+                    u5[k] = row_sum(swap16_add(v10[2 * k], v10[2 * k + 1]));
+                const int row = lane >> 4;
+                const int comp0 = ((row & 1) << 1) | (row >> 1);
+#if VINGS_ABLATE == 2  // timing experiment: reduction kept, LDS atomics dropped
+#pragma unroll
+                for (int k = 0; k < kGrad / 4; ++k) asm volatile("" ::"v"(u5[k]));
+#else
+                if ((lane & 15) == 0) {
+#pragma unroll
+                    for (int k = 0; k < kGrad / 4; ++k)
+                        if (u5[k] != 0.f) atomicAdd(&acc[j * kGrad + 4 * k + comp0], u5[k]);
+                }
+#endif
             }
+            cur = nxt; j = jn; has = hasn;
         }
         __syncthreads();
         // flush: consecutive lanes write consecutive floats of the accumulator
         for (int k = threadIdx.x; k < cnt * kGrad; k += 256) {
             const float v = acc[k];
+#if VINGS_ABLATE == 3   // timing experiment: no global flush (wrong results)
+            asm volatile("" ::"v"(v));
+            if (false) {
+#else
             if (v != 0.f) {
-                const int j = k / kGrad, c = k - j * kGrad;
-                atomicAdd(&dgeom[(size_t)ids[j] * kGrad + c], v);
+#endif
+                const int jj = k / kGrad, c = k - jj * kGrad;
+                atomicAdd(&dgeom[(size_t)ids[jj] * kGrad + c], v);
             }
         }
     }
@@ -361,7 +506,7 @@ extern "C" int vings_surfel_blend_backward(int N, int H, int W, const uint32_t* 
     VINGS_REQUIRE(ranges && bg && final_T && n_contrib && dL_dcolor && dL_dallmap && dgeom,
                   "null pointer");
     hipStream_t s = (hipStream_t)stream;
-    VINGS_CHECK_HIP(hipMemsetAsync(dgeom, 0, sizeof(float) * (size_t)N * VINGS_GEOM_STRIDE, s));
+    VINGS_CHECK_HIP(hipMemsetAsync(dgeom, 0, sizeof(float) * (size_t)N * VINGS_GRAD_STRIDE, s));
     const int gx = (W + 15) / 16, gy = (H + 15) / 16;
     ProfScope prof(PROF_BLEND_BWD, s);
     blend_bwd_kernel<<<gx * gy, 256, 0, s>>>(H, W, gx, ranges, vals_sorted, geom, bg, pixel_mask,

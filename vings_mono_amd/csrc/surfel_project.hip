@@ -155,6 +155,37 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
             g[2] = make_float4(f.A[2][2], cx, cy, f.mult * f.n[0]);
             g[3] = make_float4(f.mult * f.n[1], f.mult * f.n[2], o, c0);
             g[4] = make_float4(c1, c2, fl0, fl1);
+            // Conservative pixel box of alpha >= 1/255: alpha = o * exp(-rho/2) with
+            // rho = min(rho3d, rho2d), so a pixel contributes only where rho <= rc.
+            // {rho3d <= rc} is the projected ellipse of radius sqrt(rc) (same tangent-line
+            // bound as the 3-sigma box, exact while the ellipse stays in front of the
+            // camera plane, d < 0); {rho2d <= rc} is a disc of radius sqrt(rc/2) about xy.
+            float bx0 = 1e30f, bx1 = -1e30f, by0 = 1e30f, by1 = -1e30f;   // empty
+            if (255.f * o >= 0.999f) {
+                const float rc = 2.f * logf(255.f * o) * 1.002f + 0.02f;
+                const float* Tu = f.A[0];
+                const float* Tv = f.A[1];
+                const float* Tw = f.A[2];
+                const float dd = rc * Tw[0] * Tw[0] + rc * Tw[1] * Tw[1] - Tw[2] * Tw[2];
+                if (dd < 0.f) {
+                    const float fi = 1.f / dd;
+                    const float ccx = fi * (rc * Tu[0] * Tw[0] + rc * Tu[1] * Tw[1] - Tu[2] * Tw[2]);
+                    const float ccy = fi * (rc * Tv[0] * Tw[0] + rc * Tv[1] * Tw[1] - Tv[2] * Tw[2]);
+                    const float hx2 = ccx * ccx - fi * (rc * Tu[0] * Tu[0] + rc * Tu[1] * Tu[1] - Tu[2] * Tu[2]);
+                    const float hy2 = ccy * ccy - fi * (rc * Tv[0] * Tv[0] + rc * Tv[1] * Tv[1] - Tv[2] * Tv[2]);
+                    const float hx = sqrtf(fmaxf(0.f, hx2)), hy = sqrtf(fmaxf(0.f, hy2));
+                    const float rr = sqrtf(0.5f * rc);
+                    const float slack = 0.5f + 1e-4f * (fabsf(ccx) + fabsf(ccy) + hx + hy);
+                    bx0 = fminf(ccx - hx, cx - rr) - slack; bx1 = fmaxf(ccx + hx, cx + rr) + slack;
+                    by0 = fminf(ccy - hy, cy - rr) - slack; by1 = fmaxf(ccy + hy, cy + rr) + slack;
+                    if (!(bx0 == bx0 && bx1 == bx1 && by0 == by0 && by1 == by1)) {
+                        bx0 = by0 = -1e30f; bx1 = by1 = 1e30f;
+                    }
+                } else {
+                    bx0 = by0 = -1e30f; bx1 = by1 = 1e30f;   // crosses the camera plane: no bound
+                }
+            }
+            g[5] = make_float4(bx0, bx1, by0, by1);
         }
     }
     // per-block instance count (feeds the exclusive scan over blocks)
@@ -201,7 +232,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
     float dm[3] = {0, 0, 0}, ds[2] = {0, 0}, dq[4] = {0, 0, 0, 0};
     float dop = 0, dc[3] = {0, 0, 0}, dxy[2] = {0, 0}, sc[2] = {0, 0};
     if (radii[i] > 0) {
-        const float4* g4 = reinterpret_cast<const float4*>(dgeom + (size_t)i * VINGS_GEOM_STRIDE);
+        const float4* g4 = reinterpret_cast<const float4*>(dgeom + (size_t)i * VINGS_GRAD_STRIDE);
         const float4 g0 = g4[0], g1 = g4[1], g2 = g4[2], g3 = g4[3], g4v = g4[4];
         float dA[3][3] = {{g0.x, g0.y, g0.z}, {g0.w, g1.x, g1.y}, {g1.z, g1.w, g2.x}};
         dxy[0] = g2.y; dxy[1] = g2.z;

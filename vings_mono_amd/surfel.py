@@ -15,7 +15,8 @@ import torch
 from . import _lib
 from ._lib import check, ptr, stream_ptr
 
-GEOM_STRIDE = 20
+GEOM_STRIDE = 24
+GRAD_STRIDE = 20
 LAST_INSTANCE_COUNT = 0  # D of the most recent forward pass (diagnostics)
 AUX_CHANNELS = 9
 TILE = 16
@@ -123,7 +124,7 @@ def rasterize_backward(st, aux, means3D, scales, rotations, scale_modifier, g_co
     view, proj, bg, mask, _ = aux
     N, H, W = st.N, st.H, st.W
     stream = stream_ptr(dev)
-    dgeom = torch.empty((max(N, 1), GEOM_STRIDE), dtype=torch.float32, device=dev)
+    dgeom = torch.empty((max(N, 1), GRAD_STRIDE), dtype=torch.float32, device=dev)
     check(L.vings_surfel_blend_backward(
         N, H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg), ptr(mask), ptr(st.final_T),
         ptr(st.n_contrib), ptr(g_color), ptr(g_allmap), ptr(dgeom), stream),
