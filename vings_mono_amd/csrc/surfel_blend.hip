@@ -8,12 +8,15 @@
 // ballot per (loader wave, strip).  A render wave then walks only the set bits
 // of its own four ballots with scalar bit scans, so splats that cannot reach
 // the strip cost nothing, and reads each surviving record as an LDS broadcast
-// (every lane the same address: no bank conflicts), one record ahead of use.
+// (every lane the same address: no bank conflicts).  Both kernels are bound by
+// vector-ALU issue (a wave64 instruction occupies a 16-lane SIMD for 4 cycles),
+// so the design rule is "fewest VALU instructions per (wave, splat) pair".
 //
 // Backward walks the same bits back to front.  Per splat the 20 partial
-// gradients of the contributing pixels are summed over each 16-lane DPP row,
-// the rows of the four waves meet in an LDS accumulator for the batch, and each
-// batch is flushed with one global float atomic per (splat, component).
+// gradients of the contributing pixels are summed over the wave with a
+// transposing permlane-swap tree, the four waves meet in an LDS accumulator for
+// the batch, and each batch is flushed with one global float atomic per
+// (splat, component).
 //
 // Serves GaussianRasterizer.forward / backward as called at
 // /root/reference/scripts/gaussian/gaussian_base.py:193-203,382 and consumed
@@ -31,9 +34,6 @@ constexpr float kTMin = 0.0001f;
 constexpr int kBatch = 256;
 constexpr int kRec4 = VINGS_GEOM_STRIDE / 4;  // float4 per record
 constexpr int kGrad = VINGS_GRAD_STRIDE;      // gradient components per splat
-#ifndef VINGS_ABLATE
-#define VINGS_ABLATE 0
-#endif
 
 struct Splat {  // unpacked view of one record
     float Tu[3], Tv[3], Tw[3];
@@ -66,7 +66,7 @@ __device__ __forceinline__ Splat unpack(const Rec5& q) {
 }
 
 struct Hit {
-    float kx, ky, kz, lx, ly, lz, pz, sx, sy, rho3d, rho2d, dx, dy, depth, G, alpha;
+    float kx, ky, kz, lx, ly, lz, pz, rz, sx, sy, rho3d, rho2d, dx, dy, depth, G, alpha;
 };
 
 // Ray / splat intersection and opacity at pixel (fx, fy); false = no contribution.
@@ -76,20 +76,21 @@ __device__ __forceinline__ bool eval_hit(const Splat& s, float fx, float fy, Hit
     const float px = h.ky * h.lz - h.kz * h.ly;
     const float py = h.kz * h.lx - h.kx * h.lz;
     h.pz = h.kx * h.ly - h.ky * h.lx;
-    if (h.pz == 0.f) return false;
-    const float rz = 1.0f / h.pz;
-    h.sx = px * rz; h.sy = py * rz;
+    // Straight-line on purpose: every lane evaluates everything and the rejections are
+    // folded into one predicate.  Early returns here turn every accumulator of the caller
+    // into a chain of phi copies (dozens of v_mov per splat); a lane that fails a test
+    // may carry inf/NaN in h, which the callers only read under the returned predicate.
+    h.rz = rcp_fast(h.pz);
+    h.sx = px * h.rz; h.sy = py * h.rz;
     h.rho3d = h.sx * h.sx + h.sy * h.sy;
     h.dx = s.cx - fx; h.dy = s.cy - fy;
     h.rho2d = kFilterInvSq * (h.dx * h.dx + h.dy * h.dy);
     const float rho = fminf(h.rho3d, h.rho2d);
     h.depth = (h.rho3d <= h.rho2d) ? (h.sx * s.Tw[0] + h.sy * s.Tw[1]) + s.Tw[2] : s.Tw[2];
-    if (h.depth < kNearN) return false;
     const float power = -0.5f * rho;
-    if (power > 0.f) return false;
     h.G = __expf(power);
     h.alpha = fminf(kAlphaMax, s.opa * h.G);
-    return h.alpha >= kAlphaMin;
+    return (h.pz != 0.f) & !(h.depth < kNearN) & !(power > 0.f) & (h.alpha >= kAlphaMin);
 }
 
 // Gather this lane's record of the batch into LDS and publish, per strip of the
@@ -195,41 +196,33 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(
         HitWalk walk;
         walk.begin_forward(hit, wv);
         int j;
-        bool has = walk.next_forward(j);
-        Rec5 cur;
-        if (has) cur = load_rec(rec + j * (kRec4 - 1));
-        while (has) {
-            int jn;
-            const bool hasn = walk.next_forward(jn);
-            Rec5 nxt;
-            if (hasn) nxt = load_rec(rec + jn * (kRec4 - 1));  // one record ahead of use
+        // no software prefetch here: the forward kernel is light on registers, so 6-7
+        // resident waves per SIMD hide the LDS latency better than a second record would
+        while (walk.next_forward(j)) {
             if (__ballot(!done) == 0ull) break;  // every pixel of this wave has saturated
-            if (!done) {
-                const uint32_t contributor = (base - r0) + (uint32_t)j + 1u;  // 1-based position
-                const Splat s = unpack(cur);
-                Hit h;
-                if (eval_hit(s, fx, fy, h)) {
-                    const float test_T = T * (1.f - h.alpha);
-                    if (test_T < kTMin) {
-                        done = true;
-                    } else {
-                        const float w = h.alpha * T;
-                        const float A = 1.f - T;
-                        const float m = c1 * (1.f - kNearN / h.depth);
-                        dist += (m * m * A + M2 - 2.f * m * M1) * w;
-                        Dd += h.depth * w;
-                        M1 += m * w;
-                        M2 += m * m * w;
-                        if (T > 0.5f) { med = h.depth; medc = contributor; }
-                        N0 += s.n[0] * w; N1 += s.n[1] * w; N2 += s.n[2] * w;
-                        C0 += s.rgb[0] * w; C1 += s.rgb[1] * w; C2 += s.rgb[2] * w;
-                        F0 += s.fl[0] * w; F1 += s.fl[1] * w;
-                        T = test_T;
-                        last = contributor;
-                    }
-                }
+            const uint32_t contributor = (base - r0) + (uint32_t)j + 1u;  // 1-based position
+            const Splat s = unpack(load_rec(rec + j * (kRec4 - 1)));
+            Hit h;
+            bool c = eval_hit(s, fx, fy, h) & !done;
+            const float test_T = T * (1.f - h.alpha);
+            const bool sat = c & (test_T < kTMin);
+            done |= sat;
+            c &= !sat;
+            if (c) {  // the only divergent region: accumulators update in place
+                const float w = h.alpha * T;
+                const float A = 1.f - T;
+                const float m = c1 * (1.f - kNearN * rcp_fast(h.depth));
+                dist += (m * m * A + M2 - 2.f * m * M1) * w;
+                Dd += h.depth * w;
+                M1 += m * w;
+                M2 += m * m * w;
+                if (T > 0.5f) { med = h.depth; medc = contributor; }
+                N0 += s.n[0] * w; N1 += s.n[1] * w; N2 += s.n[2] * w;
+                C0 += s.rgb[0] * w; C1 += s.rgb[1] * w; C2 += s.rgb[2] * w;
+                F0 += s.fl[0] * w; F1 += s.fl[1] * w;
+                T = test_T;
+                last = contributor;
             }
-            cur = nxt; j = jn; has = hasn;
         }
     }
     if (!inside) return;
@@ -321,11 +314,13 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
     const float c1 = kFarN / (kFarN - kNearN);
     const float c2 = (kFarN * kNearN) / (kFarN - kNearN);
 
-    float T = T_final, last_alpha = 0.f;
-    float accC0 = 0, accC1 = 0, accC2 = 0, lastC0 = 0, lastC1 = 0, lastC2 = 0;
-    float accN0 = 0, accN1 = 0, accN2 = 0, lastN0 = 0, lastN1 = 0, lastN2 = 0;
-    float accF0 = 0, accF1 = 0, lastF0 = 0, lastF1 = 0;
-    float accD = 0, lastD = 0, accA = 0, accW = 0, lastW = 0;
+    // Every blended channel c obeys the same back-to-front recurrence
+    //   acc_c <- last_alpha * last_c + (1 - last_alpha) * acc_c
+    // and enters dL/dalpha only through sum_c (value_c - acc_c) * dL/dchannel_c.  The
+    // recurrence is linear with channel-independent coefficients, so the weighted sum
+    // B = sum_c acc_c * dL/dchannel_c follows it too, fed by the previous contributor's
+    // S = sum_c value_c * dL/dchannel_c: one scalar pair replaces 14 per-channel pairs.
+    float T = T_final, last_alpha = 0.f, B = 0.f, S_last = 0.f;
 
     const int nbatch = (int)((maxlast + kBatch - 1) / kBatch);
     for (int b = nbatch - 1; b >= 0; --b) {
@@ -339,96 +334,68 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
         HitWalk walk;
         walk.begin_backward(hit, wv);
         int j;
-        bool has = walk.next_backward(j);
-        Rec5 cur;
-        if (has) cur = load_rec(rec + j * (kRec4 - 1));
-        while (has) {
-            int jn;
-            const bool hasn = walk.next_backward(jn);
-            Rec5 nxt;
-            if (hasn) nxt = load_rec(rec + jn * (kRec4 - 1));  // one record ahead of use
+        while (walk.next_backward(j)) {
             const uint32_t pos = bstart + j;
+            const Splat s = unpack(load_rec(rec + j * (kRec4 - 1)));
+            Hit h;
+            const bool c = eval_hit(s, fx, fy, h) & (pos < last);
+            if (__ballot(c) == 0ull) continue;  // wave-uniform: nobody in the strip is touched
+            // No divergent region below: every lane runs the same instructions and idle lanes
+            // are neutralised through a few selected roots (alpha, depth, G, sx, sy, rz = 0 or
+            // 1), which makes all of their 20 partial gradients exact zeros.  A branch here
+            // would cost more in phi copies and zero fills than the selects do.
+            const bool c3 = c & (h.rho3d <= h.rho2d);  // ray-splat intersection drives G
+            const float alpha = c ? h.alpha : 0.f;
+            const float r_one_m = rcp_fast(1.f - alpha);  // exactly 1 for idle lanes
+            T = T * r_one_m;
+            const float w = alpha * T;
+            const float depth = c ? h.depth : 1.f;
+            const float G = c ? h.G : 0.f;
+            // distortion weight of this splat (the per-pixel moments are final ones)
+            const float rd = rcp_fast(depth);
+            const float m = c1 * (1.f - kNearN * rd);
+            const float dm_dd = c2 * rd * rd;
+            const float Wd = (M2f + m * m * A_final - 2.f * m * M1f) * gDist;
+            // S = sum over channels of value * dL/dchannel (alpha channel value is 1)
+            float S = gA + Wd;
+            S += s.rgb[0] * gC0 + s.rgb[1] * gC1 + s.rgb[2] * gC2;
+            S += s.fl[0] * gF0 + s.fl[1] * gF1;
+            S += s.n[0] * gN0 + s.n[1] * gN1 + s.n[2] * gN2;
+            S += depth * gD;
+            const float Bn = last_alpha * S_last + (1.f - last_alpha) * B;
+            const float dL_dalpha = c ? (S - Bn) * T - (T_final * r_one_m) * bg_dot : 0.f;
+            B = c ? Bn : B;
+            S_last = c ? S : S_last;
+            last_alpha = c ? alpha : last_alpha;
+            float dL_dz = 2.f * w * (m * A_final - M1f) * gDist * dm_dd + w * gD;
+            dL_dz += (c & (pos + 1 == medc)) ? gMed : 0.f;
             float g[kGrad];
-#pragma unroll
-            for (int k = 0; k < kGrad; ++k) g[k] = 0.f;
-            bool contrib = false;
-            if (pos < last) {
-                const Splat s = unpack(cur);
-                Hit h;
-                if (eval_hit(s, fx, fy, h)) {
-                    contrib = true;
-                    const float alpha = h.alpha;
-                    const float one_m = 1.f - alpha;
-                    T = T / one_m;
-                    const float w = alpha * T;
-                    float dL_dalpha = 0.f;
-                    accC0 = last_alpha * lastC0 + (1.f - last_alpha) * accC0; lastC0 = s.rgb[0];
-                    accC1 = last_alpha * lastC1 + (1.f - last_alpha) * accC1; lastC1 = s.rgb[1];
-                    accC2 = last_alpha * lastC2 + (1.f - last_alpha) * accC2; lastC2 = s.rgb[2];
-                    dL_dalpha += (s.rgb[0] - accC0) * gC0 + (s.rgb[1] - accC1) * gC1 +
-                                 (s.rgb[2] - accC2) * gC2;
-                    g[15] = w * gC0; g[16] = w * gC1; g[17] = w * gC2;
-                    accF0 = last_alpha * lastF0 + (1.f - last_alpha) * accF0; lastF0 = s.fl[0];
-                    accF1 = last_alpha * lastF1 + (1.f - last_alpha) * accF1; lastF1 = s.fl[1];
-                    dL_dalpha += (s.fl[0] - accF0) * gF0 + (s.fl[1] - accF1) * gF1;
-                    // distortion
-                    float dL_dz = 0.f;
-                    const float rd = 1.0f / h.depth;
-                    const float m = c1 * (1.f - kNearN * rd);
-                    const float dm_dd = c2 * rd * rd;
-                    if (pos + 1 == medc) dL_dz += gMed;
-                    const float Wd = (M2f + m * m * A_final - 2.f * m * M1f) * gDist;
-                    accW = last_alpha * lastW + (1.f - last_alpha) * accW; lastW = Wd;
-                    dL_dalpha += Wd - accW;
-                    dL_dz += 2.f * w * (m * A_final - M1f) * gDist * dm_dd;
-                    // alpha channel
-                    accA = last_alpha + (1.f - last_alpha) * accA;
-                    dL_dalpha += (1.f - accA) * gA;
-                    // depth channel
-                    accD = last_alpha * lastD + (1.f - last_alpha) * accD; lastD = h.depth;
-                    dL_dalpha += (h.depth - accD) * gD;
-                    // normal channels
-                    accN0 = last_alpha * lastN0 + (1.f - last_alpha) * accN0; lastN0 = s.n[0];
-                    accN1 = last_alpha * lastN1 + (1.f - last_alpha) * accN1; lastN1 = s.n[1];
-                    accN2 = last_alpha * lastN2 + (1.f - last_alpha) * accN2; lastN2 = s.n[2];
-                    dL_dalpha += (s.n[0] - accN0) * gN0 + (s.n[1] - accN1) * gN1 +
-                                 (s.n[2] - accN2) * gN2;
-                    g[11] = w * gN0; g[12] = w * gN1; g[13] = w * gN2;
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha += (-T_final / one_m) * bg_dot;
-                    g[18] = w;
-                    g[19] = w * gabs;
-                    const float dL_dG = s.opa * dL_dalpha;
-                    g[14] = h.G * dL_dalpha;
-                    dL_dz += w * gD;
-                    if (h.rho3d <= h.rho2d) {
-                        const float dsx = dL_dG * -h.G * h.sx + dL_dz * s.Tw[0];
-                        const float dsy = dL_dG * -h.G * h.sy + dL_dz * s.Tw[1];
-                        const float rz = 1.0f / h.pz;
-                        const float dpx = dsx * rz, dpy = dsy * rz;
-                        const float dpz = -(dpx * h.sx + dpy * h.sy);
-                        const float dkx = h.ly * dpz - h.lz * dpy;
-                        const float dky = h.lz * dpx - h.lx * dpz;
-                        const float dkz = h.lx * dpy - h.ly * dpx;
-                        const float dlx = dpy * h.kz - dpz * h.ky;
-                        const float dly = dpz * h.kx - dpx * h.kz;
-                        const float dlz = dpx * h.ky - dpy * h.kx;
-                        g[0] = -dkx; g[1] = -dky; g[2] = -dkz;
-                        g[3] = -dlx; g[4] = -dly; g[5] = -dlz;
-                        g[6] = fx * dkx + fy * dlx + dL_dz * h.sx;
-                        g[7] = fx * dky + fy * dly + dL_dz * h.sy;
-                        g[8] = fx * dkz + fy * dlz + dL_dz;
-                    } else {
-                        g[9] = dL_dG * (-h.G * kFilterInvSq * h.dx);
-                        g[10] = dL_dG * (-h.G * kFilterInvSq * h.dy);
-                        g[8] = dL_dz;
-                    }
-                }
-            }
-            if (__ballot(contrib) != 0ull) {  // wave-uniform
-                // sum over each 16-lane row (one pixel row of the strip) with DPP only, then
-                // one LDS float atomic per row: four rows of four waves meet in the accumulator
+            g[11] = w * gN0; g[12] = w * gN1; g[13] = w * gN2;
+            g[14] = G * dL_dalpha;
+            g[15] = w * gC0; g[16] = w * gC1; g[17] = w * gC2;
+            g[18] = w;
+            g[19] = w * gabs;
+            const float a = -(s.opa * dL_dalpha) * G;  // dL/drho * -2, zero for idle lanes
+            const float sx = c3 ? h.sx : 0.f, sy = c3 ? h.sy : 0.f, rz = c3 ? h.rz : 0.f;
+            const float dsx = a * sx + dL_dz * s.Tw[0];
+            const float dsy = a * sy + dL_dz * s.Tw[1];
+            const float dpx = dsx * rz, dpy = dsy * rz;  // rz = 0 switches the whole chain off
+            const float dpz = -(dpx * sx + dpy * sy);
+            const float dkx = h.ly * dpz - h.lz * dpy;
+            const float dky = h.lz * dpx - h.lx * dpz;
+            const float dkz = h.lx * dpy - h.ly * dpx;
+            const float dlx = dpy * h.kz - dpz * h.ky;
+            const float dly = dpz * h.kx - dpx * h.kz;
+            const float dlz = dpx * h.ky - dpy * h.kx;
+            g[0] = -dkx; g[1] = -dky; g[2] = -dkz;
+            g[3] = -dlx; g[4] = -dly; g[5] = -dlz;
+            g[6] = fx * dkx + fy * dlx + dL_dz * sx;
+            g[7] = fx * dky + fy * dly + dL_dz * sy;
+            g[8] = fx * dkz + fy * dlz + dL_dz;
+            const float a2 = c3 ? 0.f : a * kFilterInvSq;  // low-pass filter drives G instead
+            g[9] = a2 * h.dx;
+            g[10] = a2 * h.dy;
+            {
                 // Transposing reduction.  v_permlane32_swap exchanges the upper half of one
                 // register with the lower half of another, so swap + add sums a PAIR of
                 // components over lanes l / l+32 and leaves one component per half;
@@ -445,29 +412,18 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
                     u5[k] = row_sum(swap16_add(v10[2 * k], v10[2 * k + 1]));
                 const int row = lane >> 4;
                 const int comp0 = ((row & 1) << 1) | (row >> 1);
-#if VINGS_ABLATE == 2  // timing experiment: reduction kept, LDS atomics dropped
-#pragma unroll
-                for (int k = 0; k < kGrad / 4; ++k) asm volatile("" ::"v"(u5[k]));
-#else
                 if ((lane & 15) == 0) {
 #pragma unroll
                     for (int k = 0; k < kGrad / 4; ++k)
                         if (u5[k] != 0.f) atomicAdd(&acc[j * kGrad + 4 * k + comp0], u5[k]);
                 }
-#endif
             }
-            cur = nxt; j = jn; has = hasn;
         }
         __syncthreads();
         // flush: consecutive lanes write consecutive floats of the accumulator
         for (int k = threadIdx.x; k < cnt * kGrad; k += 256) {
             const float v = acc[k];
-#if VINGS_ABLATE == 3   // timing experiment: no global flush (wrong results)
-            asm volatile("" ::"v"(v));
-            if (false) {
-#else
             if (v != 0.f) {
-#endif
                 const int jj = k / kGrad, c = k - jj * kGrad;
                 atomicAdd(&dgeom[(size_t)ids[jj] * kGrad + c], v);
             }
