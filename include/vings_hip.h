@@ -148,6 +148,34 @@ int vings_sparse_adam_multi(int n_groups, float* const* params_host,
                             const float* lrs_host, const uint8_t* visible, float b1, float b2,
                             float eps, int N, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Mapping loss of one rendered view and its gradient w.r.t. the rasteriser
+ * outputs, in place of the PyTorch graph + autograd pass the reference builds
+ * per view between GaussianRasterizer.forward and .backward:
+ *   render post-processing  gaussian_base.py:205-224   (depth = A0/alpha with
+ *                           nan/inf -> 0, normals to the world frame)
+ *   depth -> normal         normal_utils.py:6-21       (central differences)
+ *   get_loss, use_sky off   loss_utils.py:110-153      (0.8 L1 + 0.2 (1-SSIM),
+ *                           normal, alpha-on-sky, depth / depth_cov, dist)
+ *   ssim                    loss_utils.py:26-57        (11x11 Gaussian, sigma 1.5)
+ * Device arrays: rgb [3,H,W], allmap [9,H,W] (rasteriser outputs), gt_rgb
+ * [3,H,W], gt_depth [H,W], gt_depth_cov [H,W]; outputs dL_drgb [3,H,W],
+ * dL_dallmap [9,H,W] (every element written), loss_out [8] = total, rgb,
+ * normal, alpha, depth, dist terms, valid-pixel count, sky-pixel count.
+ * HOST arrays: Rw2c [9] (row-major rotation of the world->camera matrix),
+ * weights [5] = rgb, depth, alpha, normal, dist (training_args.loss_weights).
+ * fu, cu belong to the row (vertical) axis, fv, cv to the column axis.
+ * Empty masks divide by 1 instead of producing NaN.  Gradients of pixels whose
+ * depth = A0/alpha is not finite are zero where autograd would give NaN.
+ * Nothing synchronises with the host.
+ */
+size_t vings_mapping_loss_workspace_bytes(int H, int W);
+int vings_mapping_loss(int H, int W, const float* rgb, const float* allmap, const float* gt_rgb,
+                       const float* gt_depth, const float* gt_depth_cov, const float* Rw2c_host,
+                       float fu, float fv, float cu, float cv, const float* weights_host,
+                       float* dL_drgb, float* dL_dallmap, float* loss_out, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
 /* ========================================================================
  * Dense bundle adjustment (droid_backends).
  *

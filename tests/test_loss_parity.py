@@ -1,0 +1,135 @@
+"""Fused HIP mapping loss (csrc/mapping_loss.hip through the C ABI) against the float64
+CPU oracle (oracle/loss_oracle.py, pinned by the reference's golden vectors).
+
+Tolerance: loss terms 1e-5 relative; gradient maps 1e-4 of each map's largest magnitude
+plus 1e-4 relative (float32 kernels against a float64 oracle).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_oracle as lo
+from vings_mono_amd import harness, synth
+
+pytestmark = pytest.mark.gpu
+
+WEIGHTS = {"rgb_loss": 1.0, "depth_loss": 0.7, "alpha_loss": 1.3, "normal_loss": 0.1, "dist_loss": 0.05}
+
+
+def _inputs(H, W, seed, sky_frac=0.1, hole_frac=0.05, empty_frac=0.05):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.rand(*s, generator=g)
+    rgb = r(3, H, W)
+    gt_rgb = (rgb + 0.1 * torch.randn(3, H, W, generator=g)).clamp(0.01, 1.0)
+    alpha = 0.2 + 0.8 * r(1, H, W)
+    # smooth depth + noise so normals are well conditioned but not trivial
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32),
+                            indexing="ij")
+    depth = 4.0 + 0.02 * xx + 0.03 * yy + torch.sin(xx / 7.0) + 0.05 * r(H, W)
+    n = torch.nn.functional.normalize(torch.randn(3, H, W, generator=g), dim=0) * alpha
+    allmap = torch.zeros(9, H, W)
+    allmap[0] = depth * alpha[0]
+    allmap[1] = alpha[0]
+    allmap[2:5] = n
+    allmap[5] = depth
+    allmap[6] = 0.01 * r(H, W)
+    allmap[7:9] = torch.randn(2, H, W, generator=g)
+    gt_depth = (depth + 0.2 * torch.randn(H, W, generator=g)).clamp(min=0.1)[None]
+    gt_cov = 0.5 + r(1, H, W)
+    sky = r(H, W) < sky_frac
+    gt_rgb[:, sky] = 0.0
+    gt_depth[:, r(H, W) < hole_frac] = 0.0
+    empty = r(H, W) < empty_frac          # pixels nothing was blended into
+    allmap[:, empty] = 0.0
+    rgb[:, empty] = 0.0
+    gt = {"rgb": gt_rgb, "depth": gt_depth, "depth_cov": gt_cov}
+    a = math.radians(20 + seed % 50)
+    R = torch.tensor([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
+    b = math.radians(10)
+    R = R @ torch.tensor([[1, 0, 0], [0, math.cos(b), -math.sin(b)], [0, math.sin(b), math.cos(b)]])
+    w2c = torch.eye(4)
+    w2c[:3, :3] = R
+    return rgb, allmap, gt, w2c, synth.intrinsic_for(W, H)
+
+
+def _check(H, W, seed, weights=WEIGHTS, **kw):
+    rgb, allmap, gt, w2c, intr = _inputs(H, W, seed, **kw)
+    dev = torch.device("cuda:0")
+    vec, d_rgb, d_all = harness.mapping_loss_hip(
+        rgb.to(dev), allmap.to(dev), {k: v.to(dev) for k, v in gt.items()}, w2c[:3, :3], intr, weights)
+    torch.cuda.synchronize()
+    o_vec, o_rgb, o_all = lo.loss_and_grads(rgb, allmap, gt, w2c, intr, weights)
+    np.testing.assert_allclose(vec.cpu().double().numpy(), o_vec.numpy(), rtol=1e-5, atol=1e-7)
+
+    def close(got, want, name):
+        got, want = got.cpu().double(), want
+        scale = float(want.abs().max())
+        err = float((got - want).abs().max())
+        assert err <= 1e-4 * scale + 1e-12, f"{name}: max err {err:.3e} vs scale {scale:.3e}"
+        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=1e-4 * scale + 1e-12,
+                                   err_msg=name)
+
+    close(d_rgb, o_rgb, "dL_drgb")
+    names = ["A0", "alpha", "n0", "n1", "n2", "median", "dist", "flow0", "flow1"]
+    for c in range(9):
+        close(d_all[c], o_all[c], "dL_dallmap[%s]" % names[c])
+    return vec
+
+
+def test_loss_and_gradients_ragged_image():
+    _check(75, 101, 3)          # not a multiple of either tile size
+
+
+def test_loss_and_gradients_tile_aligned():
+    _check(64, 96, 5)
+
+
+def test_loss_and_gradients_tiny_image():
+    _check(5, 7, 11)            # smaller than the SSIM window: padding everywhere
+
+
+def test_no_sky_no_valid_masks_do_not_divide_by_zero():
+    vec = _check(40, 50, 7, sky_frac=0.0, hole_frac=0.0)
+    assert float(vec[7]) == 0.0 and float(vec[3]) == 0.0
+    vec = _check(40, 50, 8, sky_frac=1.1)     # every pixel sky: no valid pixel at all
+    assert float(vec[6]) == 0.0 and torch.isfinite(vec).all()
+
+
+def test_zero_weights_give_zero_gradients():
+    w = dict.fromkeys(WEIGHTS, 0.0)
+    rgb, allmap, gt, w2c, intr = _inputs(33, 47, 13)
+    dev = torch.device("cuda:0")
+    vec, d_rgb, d_all = harness.mapping_loss_hip(
+        rgb.to(dev), allmap.to(dev), {k: v.to(dev) for k, v in gt.items()}, w2c[:3, :3], intr, w)
+    assert float(vec[0]) == 0.0 and float(d_rgb.abs().max()) == 0.0 and float(d_all.abs().max()) == 0.0
+
+
+def test_mapper_step_matches_torch_graph():
+    """One view of the mapping loop: the fused loss path and the PyTorch-graph path leave the
+    same parameter gradients (1e-3 of each group's largest gradient: float32 rasteriser
+    backward accumulates in a different order between runs)."""
+    dev = torch.device("cuda:0")
+    W, H = 160, 96
+    raw = synth.make_splats(4000, W, H, n_views=2, seed=77)
+    intr = synth.intrinsic_for(W, H)
+    c2w = synth.window_poses(2)
+    gt_params = {k: v.to(dev) for k, v in synth.perturb_splats(raw).items()}
+    w2c = torch.linalg.inv(c2w[1]).to(dev)
+    with torch.no_grad():
+        p = harness.render(gt_params, w2c, intr)
+        gt = {"rgb": p["rgb"].clone(), "depth": p["depth"].clone(),
+              "depth_cov": torch.ones_like(p["depth"])}
+    grads = []
+    for torch_loss in (True, False):
+        m = harness.SurfelMapper(raw, dev)
+        m.backward_view(w2c, intr, gt, torch_loss=torch_loss)
+        grads.append(({k: m.params[k].grad.clone() for k in m.NAMES}, float(m.last_loss)))
+    (ga, la), (gb, lb) = grads
+    assert abs(la - lb) <= 1e-5 * abs(la)
+    for k in ga:
+        scale = float(ga[k].abs().max())
+        assert scale > 0
+        err = float((ga[k] - gb[k]).abs().max())
+        assert err <= 1e-3 * scale, f"{k}: {err:.3e} vs {scale:.3e}"

@@ -1,0 +1,483 @@
+// Mapping loss of one rendered view and its gradient with respect to the
+// rasteriser outputs, fused into five launches (gfx950).
+//
+// Replaces, for the hot loop, the PyTorch graph the reference builds per view:
+//   render post-processing  /root/reference/scripts/gaussian/gaussian_base.py:205-224
+//   depth -> normal         /root/reference/scripts/gaussian/normal_utils.py:6-21
+//   get_loss (use_sky off)  /root/reference/scripts/gaussian/loss_utils.py:110-153
+//   ssim                    /root/reference/scripts/gaussian/loss_utils.py:26-57
+// and the autograd pass through it, i.e. everything between the rasteriser's
+// forward outputs (rgb [3,H,W], allmap [9,H,W]) and the dL/drgb, dL/dallmap it
+// is handed back in backward.  There the graph costs ~12 grouped 11x11
+// convolutions and ~100 elementwise launches per view; here:
+//
+//   count     valid / sky pixel counts (they scale every gradient)
+//   ssim_fwd  separable 11-tap Gaussian moments of (x, y, xx, yy, xy) through
+//             LDS, SSIM value, and the three partial-derivative maps
+//   ssim_bwd  the same separable filter over the derivative maps -> dL/drgb,
+//             plus the L1 term
+//   geom      depth / normal / alpha / distortion terms: depth = A0 / alpha,
+//             central-difference surface normal with its 13-pixel adjoint
+//             stencil evaluated from an LDS tile -> dL/dallmap
+//   final     the eight loss scalars
+//
+// Everything is HBM-bound streaming work (about 40 floats per pixel in total);
+// the LDS tiles exist so each input pixel is read once per kernel.
+#include "common.hpp"
+
+namespace vings {
+
+constexpr int kWin = 11, kHalo = 5;
+constexpr int kST = 32;                 // SSIM output tile (kST x kST), 256 lanes
+constexpr int kSIn = kST + 2 * kHalo;   // 42
+constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
+
+struct Gauss { float g[kWin]; };
+
+struct LossSums {          // accumulated in float64
+    double l1, ssim, normal, alpha, depth, dist;
+    unsigned int n_valid, n_sky;
+};
+
+__device__ __forceinline__ bool is_sky(const float* __restrict__ gt_rgb, size_t HW, size_t p) {
+    return (gt_rgb[p] + gt_rgb[HW + p]) + gt_rgb[2 * HW + p] == 0.0f;
+}
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    // 256 lanes: DPP-free shuffle tree per wave, then one LDS hop
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int wv = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wv] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void loss_count_kernel(size_t HW, const float* __restrict__ gt_rgb,
+                                                         const float* __restrict__ gt_depth,
+                                                         LossSums* __restrict__ sums) {
+    unsigned nv = 0, ns = 0;
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < HW; p += (size_t)gridDim.x * 256) {
+        const bool sky = is_sky(gt_rgb, HW, p);
+        ns += sky;
+        nv += (!sky) && gt_depth[p] > 0.0f;
+    }
+    nv = wave_sum_u32(nv);
+    ns = wave_sum_u32(ns);
+    if ((threadIdx.x & 63) == 0) {
+        if (nv) atomicAdd(&sums->n_valid, nv);
+        if (ns) atomicAdd(&sums->n_sky, ns);
+    }
+}
+
+// SSIM forward: per colour channel, moments through a separable Gaussian with zero
+// padding.  maps[(3*ch + m) * HW + p], m = 0..2: valid(p) * d ssim / d {mu_x, E[xx], E[xy]}.
+__global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, Gauss gw,
+                                                       const float* __restrict__ rgb,
+                                                       const float* __restrict__ gt_rgb,
+                                                       const float* __restrict__ gt_depth,
+                                                       float* __restrict__ maps,
+                                                       LossSums* __restrict__ sums) {
+    __shared__ float sx[kSIn][kSIn + 1], sy[kSIn][kSIn + 1];
+    __shared__ float hz[5][kSIn][kST + 1];
+    __shared__ double red[4];
+    const size_t HW = (size_t)H * W;
+    const int tx0 = blockIdx.x * kST, ty0 = blockIdx.y * kST;
+    const int c = threadIdx.x & 31, rq = threadIdx.x >> 5;  // output column, first output row
+    double ssim_acc = 0.0, l1_acc = 0.0;
+    // validity of this lane's four output pixels (rows rq, rq+8, rq+16, rq+24)
+    bool vld[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gy = ty0 + rq + 8 * i, gx = tx0 + c;
+        vld[i] = false;
+        if (gy < H && gx < W) {
+            const size_t p = (size_t)gy * W + gx;
+            vld[i] = !is_sky(gt_rgb, HW, p) && gt_depth[p] > 0.0f;
+        }
+    }
+    for (int ch = 0; ch < 3; ++ch) {
+        const float* __restrict__ X = rgb + ch * HW;
+        const float* __restrict__ Y = gt_rgb + ch * HW;
+        for (int idx = threadIdx.x; idx < kSIn * kSIn; idx += 256) {
+            const int r = idx / kSIn, cc = idx - r * kSIn;
+            const int gy = ty0 + r - kHalo, gx = tx0 + cc - kHalo;
+            float xv = 0.f, yv = 0.f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                xv = X[(size_t)gy * W + gx];
+                yv = Y[(size_t)gy * W + gx];
+            }
+            sx[r][cc] = xv; sy[r][cc] = yv;
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < kSIn * kST; idx += 256) {
+            const int r = idx >> 5, cc = idx & 31;
+            float m1 = 0, m2 = 0, e11 = 0, e22 = 0, e12 = 0;
+#pragma unroll
+            for (int k = 0; k < kWin; ++k) {
+                const float xv = sx[r][cc + k], yv = sy[r][cc + k], g = gw.g[k];
+                const float gx_ = g * xv, gy_ = g * yv;
+                m1 += gx_; m2 += gy_;
+                e11 += gx_ * xv; e22 += gy_ * yv; e12 += gx_ * yv;
+            }
+            hz[0][r][cc] = m1; hz[1][r][cc] = m2; hz[2][r][cc] = e11; hz[3][r][cc] = e22;
+            hz[4][r][cc] = e12;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = rq + 8 * i;
+            const int gy = ty0 + r, gx = tx0 + c;
+            float mu1 = 0, mu2 = 0, e11 = 0, e22 = 0, e12 = 0;
+#pragma unroll
+            for (int k = 0; k < kWin; ++k) {
+                const float g = gw.g[k];
+                mu1 += g * hz[0][r + k][c]; mu2 += g * hz[1][r + k][c];
+                e11 += g * hz[2][r + k][c]; e22 += g * hz[3][r + k][c];
+                e12 += g * hz[4][r + k][c];
+            }
+            if (gy < H && gx < W) {
+                const size_t p = (size_t)gy * W + gx;
+                const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+                const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+                const float a = 2.f * mu12 + kC1, b = 2.f * s12 + kC2;
+                const float cq = mu1_sq + mu2_sq + kC1, d = s1 + s2 + kC2;
+                const float rcd = 1.0f / (cq * d);
+                const float ssim = a * b * rcd;
+                const float v = vld[i] ? 1.f : 0.f;
+                // partial derivatives with (mu_x, E[xx], E[xy]) as the independent inputs
+                const float d_mu1 = 2.f * mu2 * (b - a) * rcd - 2.f * mu1 * ssim * (d - cq) * rcd;
+                const float d_e11 = -ssim / d;
+                const float d_e12 = 2.f * a * rcd;
+                maps[(size_t)(3 * ch + 0) * HW + p] = v * d_mu1;
+                maps[(size_t)(3 * ch + 1) * HW + p] = v * d_e11;
+                maps[(size_t)(3 * ch + 2) * HW + p] = v * d_e12;
+                if (vld[i]) {
+                    ssim_acc += (double)ssim;
+                    l1_acc += (double)fabsf(sx[r + kHalo][c + kHalo] - sy[r + kHalo][c + kHalo]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const double s_tot = block_sum(ssim_acc, red);
+    const double l_tot = block_sum(l1_acc, red);
+    if (threadIdx.x == 0) {
+        if (s_tot != 0.0) atomicAdd(&sums->ssim, s_tot);
+        if (l_tot != 0.0) atomicAdd(&sums->l1, l_tot);
+    }
+}
+
+// SSIM backward + L1: dL/dx(p) = w_rgb / (3 n_valid) *
+//   ( 0.8 sign(x - y) valid(p) - 0.2 [ F(M0) + 2 x F(M1) + y F(M2) ](p) ),  F = Gaussian filter.
+__global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, Gauss gw, float w_rgb,
+                                                       const float* __restrict__ rgb,
+                                                       const float* __restrict__ gt_rgb,
+                                                       const float* __restrict__ gt_depth,
+                                                       const float* __restrict__ maps,
+                                                       const LossSums* __restrict__ sums,
+                                                       float* __restrict__ dL_drgb) {
+    __shared__ float sm[3][kSIn][kSIn + 1];
+    __shared__ float hz[3][kSIn][kST + 1];
+    const size_t HW = (size_t)H * W;
+    const int tx0 = blockIdx.x * kST, ty0 = blockIdx.y * kST;
+    const int c = threadIdx.x & 31, rq = threadIdx.x >> 5;
+    const float nv = (float)max(sums->n_valid, 1u);
+    const float k_pix = w_rgb / (3.f * nv);
+    bool vld[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gy = ty0 + rq + 8 * i, gx = tx0 + c;
+        vld[i] = false;
+        if (gy < H && gx < W) {
+            const size_t p = (size_t)gy * W + gx;
+            vld[i] = !is_sky(gt_rgb, HW, p) && gt_depth[p] > 0.0f;
+        }
+    }
+    for (int ch = 0; ch < 3; ++ch) {
+        for (int idx = threadIdx.x; idx < kSIn * kSIn; idx += 256) {
+            const int r = idx / kSIn, cc = idx - r * kSIn;
+            const int gy = ty0 + r - kHalo, gx = tx0 + cc - kHalo;
+            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const size_t p = in ? (size_t)gy * W + gx : 0;
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+                sm[m][r][cc] = in ? maps[(size_t)(3 * ch + m) * HW + p] : 0.f;
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < kSIn * kST; idx += 256) {
+            const int r = idx >> 5, cc = idx & 31;
+            float f0 = 0, f1 = 0, f2 = 0;
+#pragma unroll
+            for (int k = 0; k < kWin; ++k) {
+                const float g = gw.g[k];
+                f0 += g * sm[0][r][cc + k]; f1 += g * sm[1][r][cc + k]; f2 += g * sm[2][r][cc + k];
+            }
+            hz[0][r][cc] = f0; hz[1][r][cc] = f1; hz[2][r][cc] = f2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = rq + 8 * i;
+            const int gy = ty0 + r, gx = tx0 + c;
+            float f0 = 0, f1 = 0, f2 = 0;
+#pragma unroll
+            for (int k = 0; k < kWin; ++k) {
+                const float g = gw.g[k];
+                f0 += g * hz[0][r + k][c]; f1 += g * hz[1][r + k][c]; f2 += g * hz[2][r + k][c];
+            }
+            if (gy < H && gx < W) {
+                const size_t p = (size_t)gy * W + gx;
+                const float x = rgb[ch * HW + p], y = gt_rgb[ch * HW + p];
+                const float diff = x - y;
+                const float sgn = vld[i] ? (float)((diff > 0.f) - (diff < 0.f)) : 0.f;
+                dL_drgb[ch * HW + p] =
+                    k_pix * (0.8f * sgn - 0.2f * (f0 + 2.f * x * f1 + y * f2));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+struct GeomArgs {
+    float R[9];                       // world-to-camera rotation, row major
+    float fu, fv, cu, cv;             // u = row (vertical), v = column
+    float w_normal, w_alpha, w_depth, w_dist;
+};
+
+__device__ __forceinline__ float depth_of(float a0, float alpha) {
+    const float d = a0 / alpha;
+    return (d == d && fabsf(d) != INFINITY) ? d : 0.f;   // nan / +-inf -> 0
+}
+
+constexpr int kGT = 16;  // geometry tile
+
+// Depth / normal / alpha / distortion terms -> dL/dallmap (all nine channels written).
+__global__ __launch_bounds__(256) void geom_loss_kernel(int H, int W, GeomArgs ga,
+                                                        const float* __restrict__ allmap,
+                                                        const float* __restrict__ gt_rgb,
+                                                        const float* __restrict__ gt_depth,
+                                                        const float* __restrict__ gt_cov,
+                                                        LossSums* __restrict__ sums,
+                                                        float* __restrict__ dL_dallmap) {
+    __shared__ float dep[kGT + 4][kGT + 5];
+    __shared__ float G[kGT + 2][kGT + 2][7];   // dL/d(dx), dL/d(dy) of the pixel's normal (+pad)
+    __shared__ double red[4];
+    const size_t HW = (size_t)H * W;
+    const int tx0 = blockIdx.x * kGT, ty0 = blockIdx.y * kGT;
+    const float nv = (float)max(sums->n_valid, 1u), ns = (float)max(sums->n_sky, 1u);
+    for (int idx = threadIdx.x; idx < (kGT + 4) * (kGT + 4); idx += 256) {
+        const int r = idx / (kGT + 4), cc = idx - r * (kGT + 4);
+        const int gy = ty0 + r - 2, gx = tx0 + cc - 2;
+        float d = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const size_t p = (size_t)gy * W + gx;
+            d = depth_of(allmap[p], allmap[HW + p]);
+        }
+        dep[r][cc] = d;
+    }
+    __syncthreads();
+    // camera-space point of tile-local pixel (r, cc) in dep[] coordinates
+    auto point = [&](int r, int cc, float& x, float& y, float& z) {
+        const float d = dep[r][cc];
+        const float v = (float)(tx0 + cc - 2), u = (float)(ty0 + r - 2);
+        x = (v - ga.cv) / ga.fv * d; y = (u - ga.cu) / ga.fu * d; z = d;
+    };
+    double normal_acc = 0.0;
+    for (int idx = threadIdx.x; idx < (kGT + 2) * (kGT + 2); idx += 256) {
+        const int r = idx / (kGT + 2), cc = idx - r * (kGT + 2);  // G coordinates
+        const int gy = ty0 + r - 1, gx = tx0 + cc - 1;
+        float gdx[3] = {0, 0, 0}, gdy[3] = {0, 0, 0};
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const bool owned = r >= 1 && r <= kGT && cc >= 1 && cc <= kGT;
+        if (in) {
+            const size_t p = (size_t)gy * W + gx;
+            const bool valid = !is_sky(gt_rgb, HW, p) && gt_depth[p] > 0.0f;
+            const bool interior = gy >= 1 && gy <= H - 2 && gx >= 1 && gx <= W - 2;
+            float nh[3] = {0, 0, 0};  // surface normal (camera frame); zero on the border
+            float dxv[3], dyv[3], inv_len = 0.f;
+            if (interior) {
+                float ax, ay, az, bx, by, bz;
+                point(r + 1, cc + 2, ax, ay, az); point(r + 1, cc, bx, by, bz);  // right - left
+                dxv[0] = ax - bx; dxv[1] = ay - by; dxv[2] = az - bz;
+                point(r, cc + 1, ax, ay, az); point(r + 2, cc + 1, bx, by, bz);  // up - down
+                dyv[0] = ax - bx; dyv[1] = ay - by; dyv[2] = az - bz;
+                const float c0 = dxv[1] * dyv[2] - dxv[2] * dyv[1];
+                const float c1 = dxv[2] * dyv[0] - dxv[0] * dyv[2];
+                const float c2 = dxv[0] * dyv[1] - dxv[1] * dyv[0];
+                const float len = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+                inv_len = 1.0f / fmaxf(len, 1e-12f);
+                nh[0] = c0 * inv_len; nh[1] = c1 * inv_len; nh[2] = c2 * inv_len;
+            }
+            // rendered normal taken to the world frame and back: t = R (R^T n) as the
+            // reference multiplies both normals by the rotation before the dot product
+            const float n0 = allmap[2 * HW + p], n1 = allmap[3 * HW + p], n2 = allmap[4 * HW + p];
+            float aw[3], t[3], sw[3], rs[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                aw[j] = n0 * ga.R[j] + n1 * ga.R[3 + j] + n2 * ga.R[6 + j];
+                sw[j] = nh[0] * ga.R[j] + nh[1] * ga.R[3 + j] + nh[2] * ga.R[6 + j];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                t[i] = ga.R[3 * i] * aw[0] + ga.R[3 * i + 1] * aw[1] + ga.R[3 * i + 2] * aw[2];
+                rs[i] = ga.R[3 * i] * sw[0] + ga.R[3 * i + 1] * sw[1] + ga.R[3 * i + 2] * sw[2];
+            }
+            const float kq = valid ? ga.w_normal / nv : 0.f;
+            if (owned) {
+                if (valid) normal_acc += 1.0 - (double)(aw[0] * sw[0] + aw[1] * sw[1] + aw[2] * sw[2]);
+                // d(1 - a.s)/dn = -R s: the rendered-normal channels of this pixel
+                dL_dallmap[2 * HW + p] = -kq * rs[0];
+                dL_dallmap[3 * HW + p] = -kq * rs[1];
+                dL_dallmap[4 * HW + p] = -kq * rs[2];
+            }
+            if (interior && kq != 0.f) {
+                // g = dL/dn_hat = -kq t ; through the normalisation, then the cross product
+                const float g0 = -kq * t[0], g1 = -kq * t[1], g2 = -kq * t[2];
+                const float ng = nh[0] * g0 + nh[1] * g1 + nh[2] * g2;
+                const float dc0 = (g0 - nh[0] * ng) * inv_len, dc1 = (g1 - nh[1] * ng) * inv_len,
+                            dc2 = (g2 - nh[2] * ng) * inv_len;
+                gdx[0] = dyv[1] * dc2 - dyv[2] * dc1;   // dy x dc
+                gdx[1] = dyv[2] * dc0 - dyv[0] * dc2;
+                gdx[2] = dyv[0] * dc1 - dyv[1] * dc0;
+                gdy[0] = dc1 * dxv[2] - dc2 * dxv[1];   // dc x dx
+                gdy[1] = dc2 * dxv[0] - dc0 * dxv[2];
+                gdy[2] = dc0 * dxv[1] - dc1 * dxv[0];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { G[r][cc][k] = gdx[k]; G[r][cc][3 + k] = gdy[k]; }
+    }
+    __syncthreads();
+    // owned pixel of this lane
+    const int lr = threadIdx.x >> 4, lc = threadIdx.x & 15;
+    const int gy = ty0 + lr, gx = tx0 + lc;
+    double alpha_acc = 0.0, depth_acc = 0.0, dist_acc = 0.0;
+    if (gy < H && gx < W) {
+        const size_t p = (size_t)gy * W + gx;
+        const int r = lr + 1, cc = lc + 1;  // G coordinates
+        const bool sky = is_sky(gt_rgb, HW, p);
+        const bool valid = !sky && gt_depth[p] > 0.0f;
+        // P(p) enters dx of the left neighbour (+), of the right neighbour (-),
+        // dy of the lower neighbour (+) and of the upper neighbour (-)
+        float dP[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            dP[k] = G[r][cc - 1][k] - G[r][cc + 1][k] + G[r + 1][cc][3 + k] - G[r - 1][cc][3 + k];
+        const float rx = ((float)gx - ga.cv) / ga.fv, ry = ((float)gy - ga.cu) / ga.fu;
+        float dL_dd = rx * dP[0] + ry * dP[1] + dP[2];
+        const float a0 = allmap[p], alpha = allmap[HW + p];
+        const float q = a0 / alpha;
+        const bool finite = (q == q) && fabsf(q) != INFINITY;
+        const float d = finite ? q : 0.f;
+        if (valid) {
+            const float diff = d - gt_depth[p];
+            const float wgt = 1.0f / gt_cov[p];
+            depth_acc = (double)(fabsf(diff) * wgt);
+            dL_dd += ga.w_depth / nv * wgt * (float)((diff > 0.f) - (diff < 0.f));
+            dist_acc = (double)allmap[6 * HW + p];
+        }
+        if (sky) alpha_acc = (double)alpha;
+        float dA0 = 0.f, dAlpha = sky ? ga.w_alpha / ns : 0.f;
+        if (finite) {
+            dA0 = dL_dd / alpha;
+            dAlpha += -dL_dd * d / alpha;
+        }
+        dL_dallmap[p] = dA0;
+        dL_dallmap[HW + p] = dAlpha;
+        dL_dallmap[5 * HW + p] = 0.f;
+        dL_dallmap[6 * HW + p] = valid ? ga.w_dist / nv : 0.f;
+        dL_dallmap[7 * HW + p] = 0.f;
+        dL_dallmap[8 * HW + p] = 0.f;
+    }
+    const double n_tot = block_sum(normal_acc, red);
+    const double a_tot = block_sum(alpha_acc, red);
+    const double d_tot = block_sum(depth_acc, red);
+    const double s_tot = block_sum(dist_acc, red);
+    if (threadIdx.x == 0) {
+        if (n_tot != 0.0) atomicAdd(&sums->normal, n_tot);
+        if (a_tot != 0.0) atomicAdd(&sums->alpha, a_tot);
+        if (d_tot != 0.0) atomicAdd(&sums->depth, d_tot);
+        if (s_tot != 0.0) atomicAdd(&sums->dist, s_tot);
+    }
+}
+
+// out[0..7] = total, rgb, normal, alpha, depth, dist loss terms (unweighted), n_valid, n_sky
+__global__ void loss_final_kernel(const LossSums* __restrict__ sums, float w_rgb, float w_normal,
+                                  float w_alpha, float w_depth, float w_dist,
+                                  float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double nv = (double)max(sums->n_valid, 1u), ns = (double)max(sums->n_sky, 1u);
+    const double l1 = sums->l1 / (3.0 * nv), ssim = sums->ssim / (3.0 * nv);
+    const double rgb = 0.8 * l1 + 0.2 * (1.0 - ssim);
+    const double normal = sums->normal / nv, alpha = sums->alpha / ns;
+    const double depth = sums->depth / nv, dist = sums->dist / nv;
+    out[0] = (float)(w_rgb * rgb + w_normal * normal + w_alpha * alpha + w_depth * depth +
+                     w_dist * dist);
+    out[1] = (float)rgb; out[2] = (float)normal; out[3] = (float)alpha; out[4] = (float)depth;
+    out[5] = (float)dist; out[6] = (float)sums->n_valid; out[7] = (float)sums->n_sky;
+}
+
+constexpr size_t kSumsBytes = 256;  // LossSums padded so the maps stay 256-byte aligned
+
+}  // namespace vings
+
+using namespace vings;
+
+extern "C" size_t vings_mapping_loss_workspace_bytes(int H, int W) {
+    return kSumsBytes + sizeof(float) * 9 * (size_t)H * (size_t)W;
+}
+
+extern "C" int vings_mapping_loss(int H, int W, const float* rgb, const float* allmap,
+                                  const float* gt_rgb, const float* gt_depth,
+                                  const float* gt_depth_cov, const float* Rw2c, float fu, float fv,
+                                  float cu, float cv, const float* weights, float* dL_drgb,
+                                  float* dL_dallmap, float* loss_out, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    VINGS_REQUIRE(H >= 3 && W >= 3, "image must be at least 3x3");
+    VINGS_REQUIRE(rgb && allmap && gt_rgb && gt_depth && gt_depth_cov && Rw2c && weights,
+                  "null input");
+    VINGS_REQUIRE(dL_drgb && dL_dallmap && loss_out && workspace, "null output");
+    VINGS_REQUIRE(workspace_bytes >= vings_mapping_loss_workspace_bytes(H, W), "workspace too small");
+    VINGS_REQUIRE(((uintptr_t)workspace & 7) == 0, "workspace must be 8-byte aligned");
+    VINGS_REQUIRE(fu != 0.f && fv != 0.f, "focal lengths");
+    hipStream_t s = (hipStream_t)stream;
+    LossSums* sums = reinterpret_cast<LossSums*>(workspace);
+    float* maps = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kSumsBytes);
+    const size_t HW = (size_t)H * W;
+    // the Gaussian window of loss_utils.py:26-28 (sigma 1.5, normalised), in float like there
+    Gauss gw;
+    {
+        float sum = 0.f;
+        for (int k = 0; k < kWin; ++k) {
+            gw.g[k] = (float)exp(-(double)((k - kWin / 2) * (k - kWin / 2)) / (2.0 * 1.5 * 1.5));
+            sum += gw.g[k];
+        }
+        for (int k = 0; k < kWin; ++k) gw.g[k] /= sum;
+    }
+    GeomArgs ga;
+    for (int k = 0; k < 9; ++k) ga.R[k] = Rw2c[k];
+    ga.fu = fu; ga.fv = fv; ga.cu = cu; ga.cv = cv;
+    const float w_rgb = weights[0], w_depth = weights[1], w_alpha = weights[2],
+                w_normal = weights[3], w_dist = weights[4];
+    ga.w_normal = w_normal; ga.w_alpha = w_alpha; ga.w_depth = w_depth; ga.w_dist = w_dist;
+
+    ProfScope prof(PROF_LOSS, s);
+    VINGS_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(LossSums), s));
+    loss_count_kernel<<<min(cdiv((int64_t)HW, 256), 2048), 256, 0, s>>>(HW, gt_rgb, gt_depth, sums);
+    VINGS_LAUNCH_CHECK();
+    const dim3 sgrid(cdiv(W, kST), cdiv(H, kST));
+    ssim_fwd_kernel<<<sgrid, 256, 0, s>>>(H, W, gw, rgb, gt_rgb, gt_depth, maps, sums);
+    VINGS_LAUNCH_CHECK();
+    ssim_bwd_kernel<<<sgrid, 256, 0, s>>>(H, W, gw, w_rgb, rgb, gt_rgb, gt_depth, maps, sums,
+                                          dL_drgb);
+    VINGS_LAUNCH_CHECK();
+    const dim3 ggrid(cdiv(W, kGT), cdiv(H, kGT));
+    geom_loss_kernel<<<ggrid, 256, 0, s>>>(H, W, ga, allmap, gt_rgb, gt_depth, gt_depth_cov, sums,
+                                           dL_dallmap);
+    VINGS_LAUNCH_CHECK();
+    loss_final_kernel<<<1, 64, 0, s>>>(sums, w_rgb, w_normal, w_alpha, w_depth, w_dist, loss_out);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}

@@ -50,6 +50,14 @@ def depth_to_normal(depth, intr):
 def render(params, w2c, intr, bg=None, pixel_mask=None, u2_minus_u1=None, scores=None,
            means2D=None):
     """Render one view; returns the dict consumed by the loss (gaussian_base.py:211-224)."""
+    rgb, radii, allmap = render_raw(params, w2c, intr, bg, pixel_mask, u2_minus_u1, scores,
+                                    means2D)
+    return postprocess(rgb, radii, allmap, w2c, intr)
+
+
+def render_raw(params, w2c, intr, bg=None, pixel_mask=None, u2_minus_u1=None, scores=None,
+               means2D=None):
+    """Render one view; returns the rasteriser's own outputs (rgb, radii, allmap)."""
     dev = params["_xyz"].device
     cam = synth.Camera(w2c, intr)
     if bg is None:
@@ -60,11 +68,10 @@ def render(params, w2c, intr, bg=None, pixel_mask=None, u2_minus_u1=None, scores
         projmatrix=cam.full_proj_transform, sh_degree=0, campos=cam.camera_center,
         prefiltered=False, debug=False, pixel_mask=pixel_mask, u2_minus_u1=u2_minus_u1)
     act = synth.activate(params)
-    rgb, radii, allmap = GaussianRasterizer(raster_settings=settings)(
+    return GaussianRasterizer(raster_settings=settings)(
         means3D=act["means3D"], means2D=means2D, shs=None, colors_precomp=act["colors"],
         opacities=act["opacities"], scales=act["scales"], rotations=act["rotations"],
         scores=scores, cov3D_precomp=None)
-    return postprocess(rgb, radii, allmap, w2c, intr)
 
 
 def postprocess(rgb, radii, allmap, w2c, intr):
@@ -127,6 +134,45 @@ def mapping_loss(pred, gt, weights=DEFAULT_LOSS_WEIGHTS):
             weights["dist_loss"] * dist_loss)
 
 
+_LOSS_WS = {}
+LOSS_WEIGHT_ORDER = ("rgb_loss", "depth_loss", "alpha_loss", "normal_loss", "dist_loss")
+
+
+def mapping_loss_hip(rgb, allmap, gt, Rw2c_host, intr, weights=DEFAULT_LOSS_WEIGHTS):
+    """`mapping_loss(postprocess(...))` and its gradient w.r.t. the rasteriser outputs in
+    five HIP launches (csrc/mapping_loss.hip) instead of a PyTorch graph.
+
+    rgb [3,H,W], allmap [9,H,W]: rasteriser outputs (device); gt: dict with rgb [3,H,W],
+    depth [1,H,W], depth_cov [1,H,W]; Rw2c_host: 3x3 CPU tensor (rotation of w2c).
+    Returns (loss_vec [8] device tensor, dL_drgb, dL_dallmap); loss_vec[0] is the total.
+    """
+    from . import _lib
+    import ctypes
+    lib = _lib.lib()
+    dev = rgb.device
+    _lib.require_gpu_tensor(rgb, "rgb", torch.float32)
+    _lib.require_gpu_tensor(allmap, "allmap", torch.float32)
+    H, W = rgb.shape[-2:]
+    key = (H, W, dev.index)
+    if key not in _LOSS_WS:
+        nbytes = lib.vings_mapping_loss_workspace_bytes(H, W)
+        _LOSS_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ws = _LOSS_WS[key]
+    d_rgb = torch.empty_like(rgb)
+    d_allmap = torch.empty_like(allmap)
+    loss_vec = torch.empty(8, dtype=torch.float32, device=dev)
+    R = (ctypes.c_float * 9)(*[float(x) for x in Rw2c_host.reshape(-1).tolist()])
+    wts = (ctypes.c_float * 5)(*[float(weights[k]) for k in LOSS_WEIGHT_ORDER])
+    gt_rgb, gt_depth, gt_cov = (gt["rgb"].contiguous(), gt["depth"].contiguous(),
+                                gt["depth_cov"].contiguous())
+    _lib.check(lib.vings_mapping_loss(
+        H, W, _lib.ptr(rgb.contiguous()), _lib.ptr(allmap.contiguous()), _lib.ptr(gt_rgb),
+        _lib.ptr(gt_depth), _lib.ptr(gt_cov), R, float(intr["fu"]), float(intr["fv"]),
+        float(intr["cu"]), float(intr["cv"]), wts, _lib.ptr(d_rgb), _lib.ptr(d_allmap),
+        _lib.ptr(loss_vec), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "vings_mapping_loss")
+    return loss_vec, d_rgb, d_allmap
+
+
 def score_weight(current_scores, global_scores):
     """Per-splat gradient weight s0 / (S0 + 1e-6 + s0), [N,1]."""
     s0 = current_scores[:, 0]
@@ -158,15 +204,30 @@ class SurfelMapper:
     def render(self, w2c, intr, scores=None):
         return render(self.params, w2c, intr, scores=scores)
 
-    def backward_view(self, w2c, intr, gt):
+    def backward_view(self, w2c, intr, gt, Rw2c_host=None, torch_loss=False):
         """Forward + loss + backward for one view; leaves .grad on the parameters.
-        Returns (radii, current_scores)."""
+        Returns (radii, current_scores).
+
+        The loss and its gradient w.r.t. the rendered maps come from the fused HIP kernels
+        (`mapping_loss_hip`); `torch_loss=True` builds the PyTorch graph of `mapping_loss`
+        instead (the formulation the fixtures pin, kept as the cross-check).  `Rw2c_host` is
+        the CPU copy of w2c[:3,:3]; passing it avoids a device->host read per view."""
         scores = torch.zeros((self.n, 2), device=self.device, requires_grad=True)
-        pred = self.render(w2c, intr, scores=scores)
-        loss = mapping_loss(pred, gt, self.loss_weights)
-        loss.backward()
-        self.last_loss = loss.detach()
-        return pred["radii"], scores.grad.detach()
+        if torch_loss:
+            pred = self.render(w2c, intr, scores=scores)
+            loss = mapping_loss(pred, gt, self.loss_weights)
+            loss.backward()
+            self.last_loss = loss.detach()
+            return pred["radii"], scores.grad.detach()
+        rgb, radii, allmap = render_raw(self.params, w2c, intr, scores=scores)
+        if Rw2c_host is None:
+            Rw2c_host = w2c[:3, :3].cpu()
+        loss_vec, d_rgb, d_allmap = mapping_loss_hip(rgb.detach(), allmap.detach(), gt, Rw2c_host,
+                                                     intr, self.loss_weights)
+        torch.autograd.backward([rgb, allmap], [d_rgb, d_allmap])
+        self.last_loss = loss_vec[0]
+        self.last_loss_terms = loss_vec
+        return radii, scores.grad.detach()
 
     def finish_view(self, radii, cur, kf_id, reducer=None):
         """Score bookkeeping, gradient weighting, (multi-GPU) gradient exchange and the
