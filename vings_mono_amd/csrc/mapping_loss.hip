@@ -34,10 +34,13 @@ constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
 struct Gauss { float g[kWin]; };
 
-struct LossSums {          // accumulated in float64
-    double l1, ssim, normal, alpha, depth, dist;
+struct LossSums {          // pixel counts; the loss sums go through per-block partials
     unsigned int n_valid, n_sky;
 };
+// Per-block partial sums (float64), reduced by loss_final_kernel.  Thousands of blocks
+// adding to one address would serialise in L2 for longer than the kernels run.
+constexpr int kSsimParts = 2;  // ssim, l1
+constexpr int kGeomParts = 4;  // normal, alpha, depth, dist
 
 __device__ __forceinline__ bool is_sky(const float* __restrict__ gt_rgb, size_t HW, size_t p) {
     return (gt_rgb[p] + gt_rgb[HW + p]) + gt_rgb[2 * HW + p] == 0.0f;
@@ -63,9 +66,14 @@ __global__ __launch_bounds__(256) void loss_count_kernel(size_t HW, const float*
         ns += sky;
         nv += (!sky) && gt_depth[p] > 0.0f;
     }
+    __shared__ unsigned cnt[2][4];
     nv = wave_sum_u32(nv);
     ns = wave_sum_u32(ns);
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0) { cnt[0][threadIdx.x >> 6] = nv; cnt[1][threadIdx.x >> 6] = ns; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        nv = cnt[0][0] + cnt[0][1] + cnt[0][2] + cnt[0][3];
+        ns = cnt[1][0] + cnt[1][1] + cnt[1][2] + cnt[1][3];
         if (nv) atomicAdd(&sums->n_valid, nv);
         if (ns) atomicAdd(&sums->n_sky, ns);
     }
@@ -78,7 +86,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, Gauss gw,
                                                        const float* __restrict__ gt_rgb,
                                                        const float* __restrict__ gt_depth,
                                                        float* __restrict__ maps,
-                                                       LossSums* __restrict__ sums) {
+                                                       double* __restrict__ partials) {
     __shared__ float sx[kSIn][kSIn + 1], sy[kSIn][kSIn + 1];
     __shared__ float hz[5][kSIn][kST + 1];
     __shared__ double red[4];
@@ -164,8 +172,8 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, Gauss gw,
     const double s_tot = block_sum(ssim_acc, red);
     const double l_tot = block_sum(l1_acc, red);
     if (threadIdx.x == 0) {
-        if (s_tot != 0.0) atomicAdd(&sums->ssim, s_tot);
-        if (l_tot != 0.0) atomicAdd(&sums->l1, l_tot);
+        double* part = partials + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kSsimParts;
+        part[0] = s_tot; part[1] = l_tot;
     }
 }
 
@@ -259,7 +267,8 @@ __global__ __launch_bounds__(256) void geom_loss_kernel(int H, int W, GeomArgs g
                                                         const float* __restrict__ gt_rgb,
                                                         const float* __restrict__ gt_depth,
                                                         const float* __restrict__ gt_cov,
-                                                        LossSums* __restrict__ sums,
+                                                        const LossSums* __restrict__ sums,
+                                                        double* __restrict__ partials,
                                                         float* __restrict__ dL_dallmap) {
     __shared__ float dep[kGT + 4][kGT + 5];
     __shared__ float G[kGT + 2][kGT + 2][7];   // dL/d(dx), dL/d(dy) of the pixel's normal (+pad)
@@ -279,10 +288,11 @@ __global__ __launch_bounds__(256) void geom_loss_kernel(int H, int W, GeomArgs g
     }
     __syncthreads();
     // camera-space point of tile-local pixel (r, cc) in dep[] coordinates
+    const float inv_fv = 1.0f / ga.fv, inv_fu = 1.0f / ga.fu;
     auto point = [&](int r, int cc, float& x, float& y, float& z) {
         const float d = dep[r][cc];
         const float v = (float)(tx0 + cc - 2), u = (float)(ty0 + r - 2);
-        x = (v - ga.cv) / ga.fv * d; y = (u - ga.cu) / ga.fu * d; z = d;
+        x = (v - ga.cv) * inv_fv * d; y = (u - ga.cu) * inv_fu * d; z = d;
     };
     double normal_acc = 0.0;
     for (int idx = threadIdx.x; idx < (kGT + 2) * (kGT + 2); idx += 256) {
@@ -396,23 +406,30 @@ __global__ __launch_bounds__(256) void geom_loss_kernel(int H, int W, GeomArgs g
     const double d_tot = block_sum(depth_acc, red);
     const double s_tot = block_sum(dist_acc, red);
     if (threadIdx.x == 0) {
-        if (n_tot != 0.0) atomicAdd(&sums->normal, n_tot);
-        if (a_tot != 0.0) atomicAdd(&sums->alpha, a_tot);
-        if (d_tot != 0.0) atomicAdd(&sums->depth, d_tot);
-        if (s_tot != 0.0) atomicAdd(&sums->dist, s_tot);
+        double* part = partials + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kGeomParts;
+        part[0] = n_tot; part[1] = a_tot; part[2] = d_tot; part[3] = s_tot;
     }
 }
 
 // out[0..7] = total, rgb, normal, alpha, depth, dist loss terms (unweighted), n_valid, n_sky
-__global__ void loss_final_kernel(const LossSums* __restrict__ sums, float w_rgb, float w_normal,
-                                  float w_alpha, float w_depth, float w_dist,
-                                  float* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void loss_final_kernel(
+    const LossSums* __restrict__ sums, const double* __restrict__ ssim_parts, int n_ssim,
+    const double* __restrict__ geom_parts, int n_geom, float w_rgb, float w_normal, float w_alpha,
+    float w_depth, float w_dist, float* __restrict__ out) {
+    __shared__ double red[4];
+    double acc[kSsimParts + kGeomParts] = {0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < n_ssim; i += 256)
+        for (int k = 0; k < kSsimParts; ++k) acc[k] += ssim_parts[(size_t)i * kSsimParts + k];
+    for (int i = threadIdx.x; i < n_geom; i += 256)
+        for (int k = 0; k < kGeomParts; ++k)
+            acc[kSsimParts + k] += geom_parts[(size_t)i * kGeomParts + k];
+    double tot[kSsimParts + kGeomParts];
+    for (int k = 0; k < kSsimParts + kGeomParts; ++k) tot[k] = block_sum(acc[k], red);
+    if (threadIdx.x != 0) return;
     const double nv = (double)max(sums->n_valid, 1u), ns = (double)max(sums->n_sky, 1u);
-    const double l1 = sums->l1 / (3.0 * nv), ssim = sums->ssim / (3.0 * nv);
+    const double ssim = tot[0] / (3.0 * nv), l1 = tot[1] / (3.0 * nv);
     const double rgb = 0.8 * l1 + 0.2 * (1.0 - ssim);
-    const double normal = sums->normal / nv, alpha = sums->alpha / ns;
-    const double depth = sums->depth / nv, dist = sums->dist / nv;
+    const double normal = tot[2] / nv, alpha = tot[3] / ns, depth = tot[4] / nv, dist = tot[5] / nv;
     out[0] = (float)(w_rgb * rgb + w_normal * normal + w_alpha * alpha + w_depth * depth +
                      w_dist * dist);
     out[1] = (float)rgb; out[2] = (float)normal; out[3] = (float)alpha; out[4] = (float)depth;
@@ -425,8 +442,15 @@ constexpr size_t kSumsBytes = 256;  // LossSums padded so the maps stay 256-byte
 
 using namespace vings;
 
+// workspace = [LossSums | ssim partials | geom partials | 9 derivative maps]
+static size_t partial_bytes(int H, int W) {
+    const size_t n = (size_t)cdiv(W, kST) * cdiv(H, kST) * kSsimParts +
+                     (size_t)cdiv(W, kGT) * cdiv(H, kGT) * kGeomParts;
+    return (n * sizeof(double) + 255) / 256 * 256;
+}
+
 extern "C" size_t vings_mapping_loss_workspace_bytes(int H, int W) {
-    return kSumsBytes + sizeof(float) * 9 * (size_t)H * (size_t)W;
+    return kSumsBytes + partial_bytes(H, W) + sizeof(float) * 9 * (size_t)H * (size_t)W;
 }
 
 extern "C" int vings_mapping_loss(int H, int W, const float* rgb, const float* allmap,
@@ -444,7 +468,11 @@ extern "C" int vings_mapping_loss(int H, int W, const float* rgb, const float* a
     VINGS_REQUIRE(fu != 0.f && fv != 0.f, "focal lengths");
     hipStream_t s = (hipStream_t)stream;
     LossSums* sums = reinterpret_cast<LossSums*>(workspace);
-    float* maps = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kSumsBytes);
+    const int n_ssim = cdiv(W, kST) * cdiv(H, kST), n_geom = cdiv(W, kGT) * cdiv(H, kGT);
+    double* ssim_parts = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + kSumsBytes);
+    double* geom_parts = ssim_parts + (size_t)n_ssim * kSsimParts;
+    float* maps = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kSumsBytes +
+                                           partial_bytes(H, W));
     const size_t HW = (size_t)H * W;
     // the Gaussian window of loss_utils.py:26-28 (sigma 1.5, normalised), in float like there
     Gauss gw;
@@ -465,19 +493,20 @@ extern "C" int vings_mapping_loss(int H, int W, const float* rgb, const float* a
 
     ProfScope prof(PROF_LOSS, s);
     VINGS_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(LossSums), s));
-    loss_count_kernel<<<min(cdiv((int64_t)HW, 256), 2048), 256, 0, s>>>(HW, gt_rgb, gt_depth, sums);
+    loss_count_kernel<<<min(cdiv((int64_t)HW, 1024), 1024), 256, 0, s>>>(HW, gt_rgb, gt_depth, sums);
     VINGS_LAUNCH_CHECK();
     const dim3 sgrid(cdiv(W, kST), cdiv(H, kST));
-    ssim_fwd_kernel<<<sgrid, 256, 0, s>>>(H, W, gw, rgb, gt_rgb, gt_depth, maps, sums);
+    ssim_fwd_kernel<<<sgrid, 256, 0, s>>>(H, W, gw, rgb, gt_rgb, gt_depth, maps, ssim_parts);
     VINGS_LAUNCH_CHECK();
     ssim_bwd_kernel<<<sgrid, 256, 0, s>>>(H, W, gw, w_rgb, rgb, gt_rgb, gt_depth, maps, sums,
                                           dL_drgb);
     VINGS_LAUNCH_CHECK();
     const dim3 ggrid(cdiv(W, kGT), cdiv(H, kGT));
     geom_loss_kernel<<<ggrid, 256, 0, s>>>(H, W, ga, allmap, gt_rgb, gt_depth, gt_depth_cov, sums,
-                                           dL_dallmap);
+                                           geom_parts, dL_dallmap);
     VINGS_LAUNCH_CHECK();
-    loss_final_kernel<<<1, 64, 0, s>>>(sums, w_rgb, w_normal, w_alpha, w_depth, w_dist, loss_out);
+    loss_final_kernel<<<1, 256, 0, s>>>(sums, ssim_parts, n_ssim, geom_parts, n_geom, w_rgb,
+                                        w_normal, w_alpha, w_depth, w_dist, loss_out);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }
