@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--views", type=int, default=8, help="keyframes per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dba", action="store_true")
+    ap.add_argument("--autograd", action="store_true",
+                    help="drive the view step through torch autograd and PyTorch bookkeeping "
+                         "instead of the fused C-ABI sequence")
     ap.add_argument("--torch-loss", action="store_true",
                     help="build the PyTorch loss graph instead of the fused HIP loss kernels")
     ap.add_argument("--dba-grid", type=str, default="135x240")
@@ -112,12 +115,18 @@ def main():
     # the loss kernels take from the host are prepared once, like the ground-truth maps
     w2c_dev = [torch.linalg.inv(c2w_all[k]) for k in my_views]
     R_host = [w[:3, :3].cpu() for w in w2c_dev]
+    cams = [harness.view_settings(w, intr) for w in w2c_dev]
 
     def step():
         for i, k in enumerate(my_views):
-            radii, cur = mapper.backward_view(w2c_dev[i], intr, gts[i], Rw2c_host=R_host[i],
-                                              torch_loss=args.torch_loss)
-            mapper.finish_view(radii, cur, k, reducer)
+            if args.autograd or args.torch_loss:
+                # the reference's formulation: PyTorch activations / autograd / bookkeeping
+                # around the rasteriser (and, with --torch-loss, the PyTorch loss graph)
+                radii, cur = mapper.backward_view(w2c_dev[i], intr, gts[i], Rw2c_host=R_host[i],
+                                                  torch_loss=args.torch_loss)
+                mapper.finish_view(radii, cur, k, reducer)
+            else:
+                mapper.fused_view(cams[i], intr, gts[i], R_host[i], k, reducer)
         if dba is not None:
             dba.run()
 

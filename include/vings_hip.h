@@ -149,6 +149,37 @@ int vings_sparse_adam_multi(int n_groups, float* const* params_host,
                             float eps, int N, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Parameter activations of get_property (gaussian_base.py:44-48,64-72):
+ * opacity = sigmoid(raw), scaling = exp(raw), rotation = raw / max(|raw|, 1e-12)
+ * (xyz and rgb are used as stored).  One launch for the three groups.
+ */
+int vings_splat_activate(int N, const float* raw_opacity, const float* raw_scaling,
+                         const float* raw_rotation, float* opacities, float* scales,
+                         float* rotations, void* stream);
+
+/* After the rasteriser backward of one view, in one launch per splat:
+ *  - chain rule through the activations above (gradients w.r.t. the stored parameters),
+ *  - weighting_grad (gaussian_utils.py:56-62): every gradient row times
+ *    s0 / (S0 + 1e-6 + s0), s0 = cur_scores[:,0], S0 = clamp(global_scores[:,0] + s0, 0, 1e4),
+ *  - visible = radii > 0 && !stable_mask (the mask SparseGaussianAdam.step gets at
+ *    gaussian_base.py:402; stable_mask may be NULL),
+ *  - if bookkeeping != 0, add_records (gaussian_model.py:163-168): global_scores[:,0] = S0,
+ *    local_scores[:,0] += s0, local_scores[:,1] = max(., cur_scores[:,1]), and the
+ *    best-keyframe record (kf_max_scores, kf_id) takes (s0, this_kf) where s0 is larger.
+ *    With several GPUs the caller reduces scores across ranks first and passes 0.
+ * d_* are gradients w.r.t. the ACTIVATED values as vings_surfel_project_backward returns
+ * them; g_* receive the weighted gradients w.r.t. the stored parameters (overwritten).
+ */
+int vings_splat_grad_finish(int N, const float* opacities, const float* scales,
+                            const float* raw_rotation, const float* d_means3D,
+                            const float* d_colors, const float* d_opacities, const float* d_scales,
+                            const float* d_rotations, const float* cur_scores, const int* radii,
+                            const uint8_t* stable_mask, float* global_scores, float* local_scores,
+                            float* kf_max_scores, int64_t* kf_id, int64_t this_kf, int bookkeeping,
+                            float* g_xyz, float* g_rgb, float* g_opacity, float* g_scaling,
+                            float* g_rotation, uint8_t* visible, void* stream);
+
+/* ------------------------------------------------------------------------
  * Mapping loss of one rendered view and its gradient w.r.t. the rasteriser
  * outputs, in place of the PyTorch graph + autograd pass the reference builds
  * per view between GaussianRasterizer.forward and .backward:

@@ -49,6 +49,45 @@ def test_depth_to_normal(gold):
     np.testing.assert_allclose(got.numpy(), gold["normal_out"], rtol=1e-5, atol=1e-6)
 
 
+def test_mapper_oracle_weight_matches_reference_weighting(gold):
+    from oracle import mapper_oracle as mo
+    w = mo.weight(gold["wg_cur"].astype(np.float64), gold["wg_glob"].astype(np.float64))[:, None]
+    for k in ("_xyz", "_rgb", "_scaling", "_rotation", "_opacity"):
+        np.testing.assert_allclose(gold["wg_in_" + k] * w, gold["wg_out_" + k], rtol=1e-6, atol=0)
+
+
+def test_mapper_oracle_activation_chain_rule_by_finite_differences():
+    from oracle import mapper_oracle as mo
+    rng = np.random.default_rng(3)
+    n = 6
+    ro, rs, rq = rng.normal(size=(n, 1)), rng.normal(size=(n, 2)) * 0.3, rng.normal(size=(n, 4))
+    co, cs, cq = rng.normal(size=(n, 1)), rng.normal(size=(n, 2)), rng.normal(size=(n, 4))
+
+    def f(ro, rs, rq):
+        o, s, q = mo.activate(ro, rs, rq)
+        return float((o * co).sum() + (s * cs).sum() + (q * cq).sum())
+
+    o, s, q = mo.activate(ro, rs, rq)
+    cur = np.stack([np.ones(n), np.zeros(n)], 1)           # weight = 1 / (1 + 1e-6 + 1)
+    d = {"means3D": np.zeros((n, 3)), "colors": np.zeros((n, 3)), "opacities": co, "scales": cs,
+         "rotations": cq}
+    out, vis, *_ = mo.grad_finish(o, s, rq, d, cur, np.ones(n, np.int32), np.zeros(n, bool),
+                                  np.zeros((n, 2)), np.zeros((n, 2)), np.zeros(n),
+                                  np.zeros(n, np.int64), 4)
+    wgt = 1.0 / (2.0 + 1e-6)
+    eps = 1e-6
+    for name, arr in (("_opacity", ro), ("_scaling", rs), ("_rotation", rq)):
+        num = np.zeros_like(arr)
+        for idx in np.ndindex(arr.shape):
+            a = arr.copy(); a[idx] += eps
+            b = arr.copy(); b[idx] -= eps
+            args_p = [a if arr is x else x for x in (ro, rs, rq)]
+            args_m = [b if arr is x else x for x in (ro, rs, rq)]
+            num[idx] = (f(*args_p) - f(*args_m)) / (2 * eps)
+        np.testing.assert_allclose(out[name], num * wgt, rtol=1e-6, atol=1e-8, err_msg=name)
+    assert vis.all()
+
+
 def test_postprocess_guarded_depth_matches_nan_to_num():
     allmap = torch.rand(9, 7, 9, dtype=lo.DT)
     allmap[1, 2, 3] = 0.0          # x / 0 -> inf -> 0

@@ -35,7 +35,7 @@ bool g_on = false;
 int g_open[PROF_NTAGS];
 const char* kTagNames[PROF_NTAGS] = {"project_fwd", "bin", "blend_fwd", "blend_bwd",
                                      "project_bwd", "adam", "dba_jacobian", "dba_schur",
-                                     "dba_solve", "dba_retract", "aux", "loss"};
+                                     "dba_solve", "dba_retract", "aux", "loss", "splat_step"};
 constexpr size_t kPool = 16384;
 }  // namespace
 

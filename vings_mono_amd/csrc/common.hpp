@@ -35,7 +35,7 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // ---- optional per-kernel HIP-event timing (off by default) -------------------
 enum ProfTag {
     PROF_PROJECT_FWD = 0, PROF_BIN, PROF_BLEND_FWD, PROF_BLEND_BWD, PROF_PROJECT_BWD, PROF_ADAM,
-    PROF_DBA_JAC, PROF_DBA_SCHUR, PROF_DBA_SOLVE, PROF_DBA_RETRACT, PROF_AUX, PROF_LOSS, PROF_NTAGS
+    PROF_DBA_JAC, PROF_DBA_SCHUR, PROF_DBA_SOLVE, PROF_DBA_RETRACT, PROF_AUX, PROF_LOSS, PROF_GLUE, PROF_NTAGS
 };
 bool prof_enabled();
 // Record an event on `s`; the pair (begin,end) is attributed to `tag`.

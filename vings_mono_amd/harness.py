@@ -55,18 +55,23 @@ def render(params, w2c, intr, bg=None, pixel_mask=None, u2_minus_u1=None, scores
     return postprocess(rgb, radii, allmap, w2c, intr)
 
 
-def render_raw(params, w2c, intr, bg=None, pixel_mask=None, u2_minus_u1=None, scores=None,
-               means2D=None):
-    """Render one view; returns the rasteriser's own outputs (rgb, radii, allmap)."""
-    dev = params["_xyz"].device
+def view_settings(w2c, intr, bg=None, pixel_mask=None, u2_minus_u1=None):
+    """The settings record the reference builds per render (gaussian_base.py:160-177) for the
+    camera `w2c` (device tensor).  A keyframe's record can be kept and reused."""
     cam = synth.Camera(w2c, intr)
     if bg is None:
-        bg = torch.zeros(3, device=dev)
-    settings = GaussianRasterizationSettings(
+        bg = torch.zeros(3, device=w2c.device)
+    return GaussianRasterizationSettings(
         image_height=cam.height, image_width=cam.width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
         bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform,
         projmatrix=cam.full_proj_transform, sh_degree=0, campos=cam.camera_center,
         prefiltered=False, debug=False, pixel_mask=pixel_mask, u2_minus_u1=u2_minus_u1)
+
+
+def render_raw(params, w2c, intr, bg=None, pixel_mask=None, u2_minus_u1=None, scores=None,
+               means2D=None):
+    """Render one view; returns the rasteriser's own outputs (rgb, radii, allmap)."""
+    settings = view_settings(w2c, intr, bg, pixel_mask, u2_minus_u1)
     act = synth.activate(params)
     return GaussianRasterizer(raster_settings=settings)(
         means3D=act["means3D"], means2D=means2D, shs=None, colors_precomp=act["colors"],
@@ -256,6 +261,64 @@ class SurfelMapper:
         self.optimizer.step(vis, self.n)
         self.optimizer.zero_grad(set_to_none=False)
         self._last_radii = radii
+
+    # ------------------------------------------------------------------ fused view step
+    def _fused_buffers(self):
+        if getattr(self, "_fb", None) is None:
+            n, dev = self.n, self.device
+            e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)
+            fb = {"opac": e(n, 1), "scales": e(n, 2), "rot": e(n, 4), "vis": e(n, dt=torch.uint8),
+                  "grads": {k: torch.zeros_like(self.params[k]) for k in self.NAMES}}
+            for k in self.NAMES:
+                self.params[k].grad = fb["grads"][k]   # the optimiser reads .grad
+            self._fb = fb
+        return self._fb
+
+    def fused_view(self, settings, intr, gt, Rw2c_host, kf_id=0, reducer=None):
+        """The same view step as backward_view + finish_view with no PyTorch op in it:
+        activations, rasteriser forward, loss, rasteriser backward, chain rule + score
+        weighting + bookkeeping, sparse Adam — 30 HIP launches through the C ABI.
+        `settings` is the view's GaussianRasterizationSettings (see `view_settings`)."""
+        from . import _lib, surfel
+        L = _lib.lib()
+        fb = self._fused_buffers()
+        P, n, dev = self.params, self.n, self.device
+        stream = _lib.stream_ptr(dev)
+        ptr = _lib.ptr
+        with torch.no_grad():
+            _lib.check(L.vings_splat_activate(n, ptr(P["_opacity"]), ptr(P["_scaling"]),
+                                              ptr(P["_rotation"]), ptr(fb["opac"]), ptr(fb["scales"]),
+                                              ptr(fb["rot"]), stream), "vings_splat_activate")
+            xyz, rgb = P["_xyz"].detach(), P["_rgb"].detach()
+            st, aux = surfel.rasterize_forward(xyz, rgb, fb["opac"], fb["scales"], fb["rot"], settings)
+            loss_vec, d_rgb, d_allmap = mapping_loss_hip(st.color, st.allmap, gt, Rw2c_host, intr,
+                                                         self.loss_weights)
+            d_xyz, _, d_col, d_opac, d_scales, d_rot, cur = surfel.rasterize_backward(
+                st, aux, xyz, fb["scales"], fb["rot"], 1.0, d_rgb, d_allmap, want_means2D=False)
+            single = reducer is None or reducer.world == 1
+            g = fb["grads"]
+            _lib.check(L.vings_splat_grad_finish(
+                n, ptr(fb["opac"]), ptr(fb["scales"]), ptr(P["_rotation"]), ptr(d_xyz), ptr(d_col),
+                ptr(d_opac), ptr(d_scales), ptr(d_rot), ptr(cur), ptr(st.radii),
+                ptr(self.stable_mask.view(torch.uint8)), ptr(self.global_scores),
+                ptr(self.local_scores), ptr(self.globalkf_max_scores), ptr(self.globalkf_id),
+                int(kf_id), 1 if single else 0, ptr(g["_xyz"]), ptr(g["_rgb"]), ptr(g["_opacity"]),
+                ptr(g["_scaling"]), ptr(g["_rotation"]), ptr(fb["vis"]), stream),
+                "vings_splat_grad_finish")
+            vis = fb["vis"]
+            if not single:
+                vis, s0_sum, s1_max, best, best_kf = reducer.reduce(g, cur, vis.bool(), kf_id)
+                self.local_scores[:, 0] += s0_sum
+                self.global_scores[:, 0] = (self.global_scores[:, 0] + s0_sum).clamp(0.0, 1e4)
+                self.local_scores[:, 1] = torch.maximum(self.local_scores[:, 1], s1_max)
+                replace = self.globalkf_max_scores < best
+                self.globalkf_max_scores = torch.where(replace, best, self.globalkf_max_scores)
+                self.globalkf_id = torch.where(replace, best_kf, self.globalkf_id)
+            self.optimizer.step(vis, n)
+        self.last_loss = loss_vec[0]
+        self.last_loss_terms = loss_vec
+        self._last_radii = st.radii
+        return loss_vec
 
     def train_view(self, c2w, intr, gt, kf_id=0, reducer=None):
         """One iteration of the reference's hot loop (gaussian_base.py:353-404)."""
