@@ -307,13 +307,16 @@ class SurfelMapper:
                 "vings_splat_grad_finish")
             vis = fb["vis"]
             if not single:
-                vis, s0_sum, s1_max, best, best_kf = reducer.reduce(g, cur, vis.bool(), kf_id)
-                self.local_scores[:, 0] += s0_sum
-                self.global_scores[:, 0] = (self.global_scores[:, 0] + s0_sum).clamp(0.0, 1e4)
-                self.local_scores[:, 1] = torch.maximum(self.local_scores[:, 1], s1_max)
-                replace = self.globalkf_max_scores < best
-                self.globalkf_max_scores = torch.where(replace, best, self.globalkf_max_scores)
-                self.globalkf_id = torch.where(replace, best_kf, self.globalkf_id)
+                # pack -> SUM / MAX all-reduce over the replicas -> unpack + bookkeeping
+                grad_ptrs = [ptr(g[k]) for k in self.NAMES]
+                _lib.check(L.vings_splat_pack_exchange(
+                    n, *grad_ptrs, ptr(vis), ptr(cur), int(kf_id), ptr(reducer.fbuf),
+                    ptr(reducer.ibuf), stream), "vings_splat_pack_exchange")
+                reducer.all_reduce_packed()
+                _lib.check(L.vings_splat_unpack_exchange(
+                    n, ptr(reducer.fbuf), ptr(reducer.ibuf), ptr(self.global_scores),
+                    ptr(self.local_scores), ptr(self.globalkf_max_scores), ptr(self.globalkf_id),
+                    *grad_ptrs, ptr(vis), stream), "vings_splat_unpack_exchange")
             self.optimizer.step(vis, n)
         self.last_loss = loss_vec[0]
         self.last_loss_terms = loss_vec

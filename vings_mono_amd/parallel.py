@@ -36,6 +36,15 @@ class GradReducer:
             self.fbuf = torch.zeros((n, PACK_WIDTH), dtype=torch.float32, device=device)
             self.ibuf = torch.zeros((n, 2), dtype=torch.int64, device=device)
 
+    def all_reduce_packed(self):
+        """SUM over `fbuf` and MAX over `ibuf`, both already filled on the device (the fused
+        view step packs them with one kernel); the two collectives run concurrently."""
+        import torch.distributed as dist
+        h1 = dist.all_reduce(self.fbuf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        h2 = dist.all_reduce(self.ibuf, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+        h1.wait()
+        h2.wait()
+
     def reduce(self, grads, cur, vis_local, kf_id):
         """grads: dict name -> [N,M] tensor (updated in place with the sum over ranks).
         Returns (vis_any[N] bool, score0_sum[N], score1_max[N], best_score0[N], best_kf[N])."""
