@@ -61,10 +61,13 @@ int vings_abi_version(void);
  *                  (rows of culled splats are left untouched)
  *      depth[N] radii[N](int32) rect[N,4](int32 x0,y0,x1,y1 in tiles)
  *      tiles_touched[N](uint32)
- *      block_prefix[ceil(N/256)+1] (uint32) exclusive prefix of per-256-splat
- *                  instance counts; last element = total
+ *      block_prefix[3*ceil(N/256)+4] (uint32): the first ceil(N/256)+1 entries are the
+ *                  exclusive prefix of per-256-splat instance counts (last = total); the
+ *                  rest is scratch for the depth range
  *      *num_instances_host  total number of (splat,tile) instances D
- * Synchronises `stream` once to return D.
+ *      depth_bits_range_host[2] (may be NULL): smallest and largest float bit pattern of
+ *                  the depths of the binned splats; hand both to vings_surfel_bin
+ * Synchronises `stream` once to return D and the range.
  */
 int vings_surfel_project(int N, int H, int W, float scale_modifier,
                          const float* means3D, const float* scales, const float* rotations,
@@ -72,7 +75,8 @@ int vings_surfel_project(int N, int H, int W, float scale_modifier,
                          const float* viewmatrix, const float* projmatrix,
                          float* geom, float* depth, int32_t* radii, int32_t* rect,
                          uint32_t* tiles_touched, uint32_t* block_prefix,
-                         int64_t* num_instances_host, void* stream);
+                         int64_t* num_instances_host, uint32_t* depth_bits_range_host,
+                         void* stream);
 
 /* Bytes of scratch vings_surfel_bin needs for D instances. */
 size_t vings_surfel_bin_workspace_bytes(int64_t D);
@@ -83,8 +87,11 @@ size_t vings_surfel_bin_workspace_bytes(int64_t D);
  * out: keys_sorted[D](uint64) vals_sorted[D](uint32 splat index)
  *      ranges[T,2](uint32 begin,end) with T = ceil(W/16)*ceil(H/16)
  * workspace: vings_surfel_bin_workspace_bytes(D) bytes, 256-byte aligned.
+ * depth_bits_min/max: the range vings_surfel_project returned (the sort skips the key bits
+ * that cannot differ); pass min > max (e.g. 1, 0) when it is not known.
  */
-int vings_surfel_bin(int N, int H, int W, int64_t D, const float* depth, const int32_t* rect,
+int vings_surfel_bin(int N, int H, int W, int64_t D, uint32_t depth_bits_min,
+                     uint32_t depth_bits_max, const float* depth, const int32_t* rect,
                      const uint32_t* tiles_touched, const uint32_t* block_prefix,
                      uint64_t* keys_sorted, uint32_t* vals_sorted, uint32_t* ranges,
                      void* workspace, size_t workspace_bytes, void* stream);

@@ -44,7 +44,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     from vings_mono_amd import _lib
     L = _lib.lib()
     d = ctypes.c_int64(-1)
-    rc = L.vings_surfel_project(10, 0, 64, 1.0, *([None] * 14), ctypes.byref(d), None)
+    rc = L.vings_surfel_project(10, 0, 64, 1.0, *([None] * 14), ctypes.byref(d), None, None)
     assert rc == -1 and b"sizes" in L.vings_last_error()
     rc = L.vings_sparse_adam(None, None, None, None, None, 0.1, 0.9, 0.999, 1e-15, 5, 3, None)
     assert rc == -1

@@ -19,10 +19,10 @@ _SIGNATURES = {
     "vings_last_error": (_c.c_char_p, []),
     "vings_abi_version": (_c.c_int, []),
     "vings_surfel_project": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float] + [_P] * 14 +
-                             [_c.POINTER(_c.c_int64), _P]),
+                             [_c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32), _P]),
     "vings_surfel_bin_workspace_bytes": (_c.c_size_t, [_c.c_int64]),
-    "vings_surfel_bin": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int64] + [_P] * 8 +
-                         [_c.c_size_t, _P]),
+    "vings_surfel_bin": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_uint32,
+                                    _c.c_uint32] + [_P] * 8 + [_c.c_size_t, _P]),
     "vings_surfel_blend_forward": (_c.c_int, [_c.c_int, _c.c_int] + [_P] * 10),
     "vings_surfel_blend_backward": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int] + [_P] * 11),
     "vings_surfel_project_backward": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float] +

@@ -1,6 +1,11 @@
 // Tile binning for the surfel rasteriser on gfx950: key emission
 // (tile << 32 | float bits of depth), a stable least-significant-digit radix
 // sort written for 64-lane wavefronts, and per-tile range extraction.
+// While sorting, the depth bits are rebased to the smallest depth of the view
+// and the tile index moved down next to them: at 1080p with depths spanning a
+// factor of 64 that is 27 + 13 bits, five 8-bit passes instead of six over
+// 32 + 13; the order is unchanged and the keys are handed out in the
+// documented form.
 //
 // The sort order is fully determined by (tile, depth bits, splat index):
 // each splat emits at most one instance per tile and instances are emitted
@@ -27,7 +32,7 @@ constexpr int kMaxPasses = 8;
 __global__ __launch_bounds__(256) void emit_keys_kernel(
     int N, int gx, const float* __restrict__ depth, const int32_t* __restrict__ rect,
     const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_prefix,
-    uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    uint32_t dmin, int low_bits, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     __shared__ uint32_t wtot[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const uint32_t cnt = i < N ? tiles_touched[i] : 0u;
@@ -39,10 +44,12 @@ __global__ __launch_bounds__(256) void emit_keys_kernel(
     for (int k = 0; k < w; ++k) off += wtot[k];
     if (cnt == 0) return;
     const int4 r = reinterpret_cast<const int4*>(rect)[i];
-    const uint32_t dbits = __float_as_uint(depth[i]);
+    // sort key: tile above the depth bits rebased to the smallest depth of the view, so the
+    // sort only runs over bits that can differ (same order as tile << 32 | depth bits)
+    const uint64_t dlow = (uint64_t)(__float_as_uint(depth[i]) - dmin);
     for (int y = r.y; y < r.w; ++y)
         for (int x = r.x; x < r.z; ++x) {
-            const uint64_t key = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;
+            const uint64_t key = ((uint64_t)(uint32_t)(y * gx + x) << low_bits) | dlow;
             keys[off] = key;
             vals[off] = (uint32_t)i;
             ++off;
@@ -90,23 +97,44 @@ __global__ __launch_bounds__(kSortThreads) void sort_tile_hist_kernel(
     thist[(size_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
-// One wave per digit: exclusive scan of that digit's row of thist, offset by
-// the number of keys with a smaller digit (from the global histogram).
-__global__ __launch_bounds__(64) void sort_scan_kernel(uint32_t* __restrict__ thist, int ntiles,
-                                                       const uint32_t* __restrict__ ghist_pass) {
+// One 256-lane workgroup per digit: exclusive scan of that digit's row of thist, offset
+// by the number of keys with a smaller digit (from the global histogram).  Each lane owns
+// 8 consecutive entries, so rows of up to 2048 sort tiles (4 M keys) take one round.
+constexpr int kScanItems = 8;
+__global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t* __restrict__ thist, int ntiles,
+                                                        const uint32_t* __restrict__ ghist_pass) {
+    __shared__ uint32_t wtot[4];
+    __shared__ uint32_t carry_s;
     const int digit = blockIdx.x;
-    const int lane = threadIdx.x;
-    uint32_t base = 0;
-    for (int k = lane; k < digit; k += 64) base += ghist_pass[k];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t base = threadIdx.x < digit ? ghist_pass[threadIdx.x] : 0u;   // digit <= 255
     base = wave_sum_u32(base);
+    if (lane == 0) wtot[w] = base;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    __syncthreads();
     uint32_t* row = thist + (size_t)digit * ntiles;
-    uint32_t carry = base;
-    for (int t0 = 0; t0 < ntiles; t0 += 64) {
-        const int t = t0 + lane;
-        const uint32_t v = t < ntiles ? row[t] : 0u;
-        const uint32_t inc = wave_scan_incl(v);
-        if (t < ntiles) row[t] = carry + inc - v;
-        carry += __shfl(inc, 63, 64);
+    for (int t0 = 0; t0 < ntiles; t0 += 256 * kScanItems) {
+        const int first = t0 + threadIdx.x * kScanItems;
+        uint32_t v[kScanItems], sum = 0;
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            v[k] = first + k < ntiles ? row[first + k] : 0u;
+            sum += v[k];
+        }
+        const uint32_t inc = wave_scan_incl(sum);
+        if (lane == 63) wtot[w] = inc;
+        __syncthreads();
+        uint32_t run = carry_s + inc - sum;
+        for (int k = 0; k < w; ++k) run += wtot[k];
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            if (first + k < ntiles) row[first + k] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = run;
+        __syncthreads();
     }
 }
 
@@ -177,19 +205,32 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(
     }
 }
 
+// Per-tile ranges from the sorted compact keys, and the keys in their documented form
+// (tile << 32 | float bits of depth) for the caller.
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint64_t* __restrict__ keys,
-                                                          int64_t D, uint32_t* __restrict__ ranges) {
+                                                          int64_t D, uint32_t dmin, int low_bits,
+                                                          uint32_t* __restrict__ ranges,
+                                                          uint64_t* __restrict__ keys_out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= D) return;
-    const uint32_t t = (uint32_t)(keys[i] >> 32);
-    if (i == 0 || (uint32_t)(keys[i - 1] >> 32) != t) ranges[2 * t] = (uint32_t)i;
-    if (i == D - 1 || (uint32_t)(keys[i + 1] >> 32) != t) ranges[2 * t + 1] = (uint32_t)(i + 1);
+    const uint64_t k = keys[i];
+    const uint32_t t = (uint32_t)(k >> low_bits);
+    if (i == 0 || (uint32_t)(keys[i - 1] >> low_bits) != t) ranges[2 * t] = (uint32_t)i;
+    if (i == D - 1 || (uint32_t)(keys[i + 1] >> low_bits) != t) ranges[2 * t + 1] = (uint32_t)(i + 1);
+    const uint32_t low = (uint32_t)(k & ((1ull << low_bits) - 1ull));
+    keys_out[i] = ((uint64_t)t << 32) | (uint64_t)(low + dmin);
 }
 
-static int sort_passes(int T) {
+static int bits_for(uint32_t span) {   // bits needed to hold values 0..span
     int bits = 0;
-    while ((1 << bits) < T) ++bits;
-    return (32 + bits + kRadixBits - 1) / kRadixBits;
+    while (bits < 32 && ((uint64_t)1 << bits) <= (uint64_t)span) ++bits;
+    return bits;
+}
+
+static int sort_passes(int T, int low_bits) {
+    const int tile_bits = bits_for((uint32_t)(T > 0 ? T - 1 : 0));
+    const int p = (low_bits + tile_bits + kRadixBits - 1) / kRadixBits;
+    return p > 0 ? p : 1;
 }
 
 struct BinWorkspace {
@@ -221,7 +262,8 @@ using namespace vings;
 
 extern "C" size_t vings_surfel_bin_workspace_bytes(int64_t D) { return carve(nullptr, D).bytes; }
 
-extern "C" int vings_surfel_bin(int N, int H, int W, int64_t D, const float* depth,
+extern "C" int vings_surfel_bin(int N, int H, int W, int64_t D, uint32_t depth_bits_min,
+                                uint32_t depth_bits_max, const float* depth,
                                 const int32_t* rect, const uint32_t* tiles_touched,
                                 const uint32_t* block_prefix, uint64_t* keys_sorted,
                                 uint32_t* vals_sorted, uint32_t* ranges, void* workspace,
@@ -243,15 +285,23 @@ extern "C" int vings_surfel_bin(int N, int H, int W, int64_t D, const float* dep
         set_error("bin workspace too small: %zu < %zu", workspace_bytes, b.bytes);
         return VINGS_ERR_CAPACITY;
     }
-    const int passes = sort_passes(T);
+    // depth bits are rebased to the view's smallest depth; an unknown range (min > max) keeps
+    // all 32 bits
+    const bool ranged = depth_bits_min <= depth_bits_max;
+    const uint32_t dmin = ranged ? depth_bits_min : 0u;
+    const int low_bits = ranged ? bits_for(depth_bits_max - depth_bits_min) : 32;
+    const int passes = sort_passes(T, low_bits);
+    VINGS_REQUIRE(passes <= kMaxPasses, "key too wide");
     ProfScope prof(PROF_BIN, s);
-    // ping-pong so that the last pass lands in keys_sorted / vals_sorted
+    // ping-pong so that the last pass leaves the (compact) keys in the workspace, from where
+    // tile_ranges writes them decoded into keys_sorted, and the values in vals_sorted
     uint64_t* kbuf[2] = {keys_sorted, b.keys_alt};
     uint32_t* vbuf[2] = {vals_sorted, b.vals_alt};
-    int cur = (passes % 2 == 0) ? 0 : 1;
+    int cur = (passes % 2 == 0) ? 1 : 0;    // keys: end in kbuf[1]
+    int vcur = (passes % 2 == 0) ? 0 : 1;   // values: end in vbuf[0]
 
     emit_keys_kernel<<<cdiv(N, 256), 256, 0, s>>>(N, gx, depth, rect, tiles_touched, block_prefix,
-                                                  kbuf[cur], vbuf[cur]);
+                                                  dmin, low_bits, kbuf[cur], vbuf[vcur]);
     VINGS_LAUNCH_CHECK();
 
     const int ntiles = cdiv(D, kSortTile);
@@ -263,16 +313,18 @@ extern "C" int vings_surfel_bin(int N, int H, int W, int64_t D, const float* dep
         const int shift = p * kRadixBits;
         sort_tile_hist_kernel<<<ntiles, kSortThreads, 0, s>>>(kbuf[cur], D, shift, ntiles, b.thist);
         VINGS_LAUNCH_CHECK();
-        sort_scan_kernel<<<kRadix, 64, 0, s>>>(b.thist, ntiles, b.ghist + p * kRadix);
+        sort_scan_kernel<<<kRadix, 256, 0, s>>>(b.thist, ntiles, b.ghist + p * kRadix);
         VINGS_LAUNCH_CHECK();
-        sort_scatter_kernel<<<ntiles, kSortThreads, 0, s>>>(kbuf[cur], vbuf[cur], kbuf[cur ^ 1],
-                                                            vbuf[cur ^ 1], D, shift, ntiles,
+        sort_scatter_kernel<<<ntiles, kSortThreads, 0, s>>>(kbuf[cur], vbuf[vcur], kbuf[cur ^ 1],
+                                                            vbuf[vcur ^ 1], D, shift, ntiles,
                                                             b.thist);
         VINGS_LAUNCH_CHECK();
         cur ^= 1;
+        vcur ^= 1;
     }
-    // cur == 0 here by construction
-    tile_ranges_kernel<<<cdiv(D, 256), 256, 0, s>>>(keys_sorted, D, ranges);
+    // cur == 1, vcur == 0 here by construction
+    tile_ranges_kernel<<<cdiv(D, 256), 256, 0, s>>>(b.keys_alt, D, dmin, low_bits, ranges,
+                                                    keys_sorted);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }

@@ -91,10 +91,12 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     const float* __restrict__ flow, const float* __restrict__ view,
     const float* __restrict__ proj, float* __restrict__ geom, float* __restrict__ depth,
     int32_t* __restrict__ radii, int32_t* __restrict__ rect, uint32_t* __restrict__ tiles_touched,
-    uint32_t* __restrict__ block_counts) {
-    __shared__ uint32_t wsum[4];
+    uint32_t* __restrict__ block_counts, uint32_t* __restrict__ block_dmin,
+    uint32_t* __restrict__ block_dmax) {
+    __shared__ uint32_t wsum[4], wmin[4], wmax[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     uint32_t touched = 0;
+    uint32_t dlo = 0xFFFFFFFFu, dhi = 0u;   // float bits of the depth of a binned splat
     if (i < N) {
         const int gx = (W + 15) / 16, gy = (H + 15) / 16;
         int32_t rad = 0;
@@ -140,6 +142,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
             }
         }
         if (!ok) { touched = 0; x0 = y0 = x1 = y1 = 0; }
+        else dlo = dhi = __float_as_uint(dep);
         radii[i] = rad;
         depth[i] = dep;
         tiles_touched[i] = touched;
@@ -190,9 +193,22 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     }
     // per-block instance count (feeds the exclusive scan over blocks)
     uint32_t s = wave_sum_u32(touched);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    // range of the depth bits (positive floats order like their bit patterns): the sort only
+    // has to cover the bits in which the keys can differ
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        dlo = min(dlo, (uint32_t)__shfl_xor(dlo, o, 64));
+        dhi = max(dhi, (uint32_t)__shfl_xor(dhi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        wsum[threadIdx.x >> 6] = s; wmin[threadIdx.x >> 6] = dlo; wmax[threadIdx.x >> 6] = dhi;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0) {
+        block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        block_dmin[blockIdx.x] = min(min(wmin[0], wmin[1]), min(wmin[2], wmin[3]));
+        block_dmax[blockIdx.x] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    }
 }
 
 // Single workgroup: in-place exclusive scan of block_counts[0..nb), total in [nb].
@@ -216,7 +232,26 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(uint32_t* __restrict_
         if (threadIdx.x == 1023) carry_s = carry + woff + inc;
         __syncthreads();
     }
-    if (threadIdx.x == 0) counts[nb] = carry_s;
+    // depth-bit range over the blocks; results live behind the per-block arrays:
+    // counts[3nb+1] = min, [3nb+2] = max, [3nb+3] = copy of the total
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    for (int i = threadIdx.x; i < nb; i += 1024) {
+        lo = min(lo, counts[nb + 1 + i]);
+        hi = max(hi, counts[2 * nb + 1 + i]);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor(lo, o, 64));
+        hi = max(hi, (uint32_t)__shfl_xor(hi, o, 64));
+    }
+    __shared__ uint32_t rlo[16], rhi[16];
+    if (lane == 0) { rlo[w] = lo; rhi[w] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; ++k) { lo = min(lo, rlo[k]); hi = max(hi, rhi[k]); }
+        counts[nb] = carry_s;
+        counts[3 * nb + 1] = lo; counts[3 * nb + 2] = hi; counts[3 * nb + 3] = carry_s;
+    }
 }
 
 __global__ __launch_bounds__(256) void project_bwd_kernel(
@@ -315,10 +350,12 @@ extern "C" int vings_surfel_project(int N, int H, int W, float scale_modifier,
                                     const float* viewmatrix, const float* projmatrix,
                                     float* geom, float* depth, int32_t* radii, int32_t* rect,
                                     uint32_t* tiles_touched, uint32_t* block_prefix,
-                                    int64_t* num_instances_host, void* stream) {
+                                    int64_t* num_instances_host, uint32_t* depth_bits_range_host,
+                                    void* stream) {
     VINGS_REQUIRE(N >= 0 && H > 0 && W > 0, "sizes");
     VINGS_REQUIRE(num_instances_host != nullptr, "num_instances_host");
     *num_instances_host = 0;
+    if (depth_bits_range_host) { depth_bits_range_host[0] = 0u; depth_bits_range_host[1] = 0xFFFFFFFFu; }
     if (N == 0) return VINGS_OK;
     VINGS_REQUIRE(means3D && scales && rotations && opacities && colors && viewmatrix &&
                       projmatrix && geom && depth && radii && rect && tiles_touched && block_prefix,
@@ -331,16 +368,21 @@ extern "C" int vings_surfel_project(int N, int H, int W, float scale_modifier,
     ProfScope prof(PROF_PROJECT_FWD, s);
     project_fwd_kernel<<<nb, 256, 0, s>>>(N, H, W, scale_modifier, means3D, scales, rotations,
                                           opacities, colors, flow, viewmatrix, projmatrix, geom,
-                                          depth, radii, rect, tiles_touched, block_prefix);
+                                          depth, radii, rect, tiles_touched, block_prefix,
+                                          block_prefix + nb + 1, block_prefix + 2 * nb + 1);
     VINGS_LAUNCH_CHECK();
     scan_blocks_kernel<<<1, 1024, 0, s>>>(block_prefix, nb);
     VINGS_LAUNCH_CHECK();
     }
-    uint32_t total = 0;
-    VINGS_CHECK_HIP(hipMemcpyAsync(&total, block_prefix + nb, sizeof(uint32_t),
+    uint32_t tail[3] = {0, 0, 0};   // depth-bit min, max, instance total
+    VINGS_CHECK_HIP(hipMemcpyAsync(tail, block_prefix + 3 * nb + 1, sizeof(tail),
                                    hipMemcpyDeviceToHost, s));
     VINGS_CHECK_HIP(hipStreamSynchronize(s));
-    *num_instances_host = (int64_t)total;
+    *num_instances_host = (int64_t)tail[2];
+    if (depth_bits_range_host && tail[2] > 0) {
+        depth_bits_range_host[0] = tail[0];
+        depth_bits_range_host[1] = tail[1];
+    }
     return VINGS_OK;
 }
 

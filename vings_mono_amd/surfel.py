@@ -84,13 +84,14 @@ def rasterize_forward(means3D, colors, opacities, scales, rotations, settings, k
     st.radii = torch.zeros(N, dtype=torch.int32, device=dev)
     st.rect = torch.empty((max(N, 1), 4), dtype=torch.int32, device=dev)
     st.tiles_touched = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
-    st.block_prefix = torch.empty(nb + 1, dtype=torch.int32, device=dev)
+    st.block_prefix = torch.empty(3 * nb + 4, dtype=torch.int32, device=dev)
     d_host = ctypes.c_int64(0)
+    d_range = (ctypes.c_uint32 * 2)(0, 0xFFFFFFFF)
     check(L.vings_surfel_project(
         N, H, W, float(settings.scale_modifier), ptr(means3D), ptr(scales), ptr(rotations),
         ptr(opacities), ptr(colors), ptr(flow), ptr(view), ptr(proj), ptr(st.geom), ptr(st.depth),
         ptr(st.radii), ptr(st.rect), ptr(st.tiles_touched), ptr(st.block_prefix),
-        ctypes.byref(d_host), stream), "vings_surfel_project")
+        ctypes.byref(d_host), d_range, stream), "vings_surfel_project")
     D = int(d_host.value)
     st.D = D
     global LAST_INSTANCE_COUNT
@@ -102,7 +103,8 @@ def rasterize_forward(means3D, colors, opacities, scales, rotations, settings, k
     ws_bytes = int(L.vings_surfel_bin_workspace_bytes(D))
     ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
     ws_ptr = (ws.data_ptr() + 255) & ~255
-    check(L.vings_surfel_bin(N, H, W, D, ptr(st.depth), ptr(st.rect), ptr(st.tiles_touched),
+    check(L.vings_surfel_bin(N, H, W, D, int(d_range[0]), int(d_range[1]), ptr(st.depth),
+                             ptr(st.rect), ptr(st.tiles_touched),
                              ptr(st.block_prefix), ptr(st.keys), ptr(st.vals), ptr(st.ranges),
                              ws_ptr, ws_bytes, stream), "vings_surfel_bin")
     st.color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
