@@ -328,14 +328,25 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(
 // backward
 // ---------------------------------------------------------------------------
 
-// Sum over the 16 lanes of a DPP row (one pixel row of the wave's strip); every
-// lane of the row receives the total.
-__device__ __forceinline__ float row_sum(float v) {
+// Sum over the 16 lanes of a DPP row; every lane of the row receives the total.
+// The last step is written as one fused v_add_f32_dpp: left to the compiler it is sunk
+// into the lane-0-only atomic region as v_mov 0 + v_mov_dpp + v_add (three issues).
+// The s_nop covers the two wait states a DPP read needs after a VALU write of its source.
+__device__ __forceinline__ float half_row_sum(float v) {
     v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
     v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
     v += dpp_f<0x141>(v);  // row_half_mirror
-    v += dpp_f<0x140>(v);  // row_mirror
     return v;
+}
+__device__ __forceinline__ void row_mirror_add5(float& a, float& b, float& c, float& d, float& e) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
 }
 
 __global__ __launch_bounds__(256) void blend_bwd_kernel(
@@ -465,8 +476,9 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
             const float dlx = dpy * h.kz - dpz * h.ky;
             const float dly = dpz * h.kx - dpx * h.kz;
             const float dlz = dpx * h.ky - dpy * h.kx;
-            g[0] = -dkx; g[1] = -dky; g[2] = -dkz;
-            g[3] = -dlx; g[4] = -dly; g[5] = -dlz;
+            // dL/dTu = -dk and dL/dTv = -dl: the sign is applied once per splat at the flush
+            g[0] = dkx; g[1] = dky; g[2] = dkz;
+            g[3] = dlx; g[4] = dly; g[5] = dlz;
             g[6] = fx * dkx + fy * dlx + dL_dz * sx;
             g[7] = fx * dky + fy * dly + dL_dz * sy;
             g[8] = fx * dkz + fy * dlz + dL_dz;
@@ -487,7 +499,8 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
                 float u5[kGrad / 4];
 #pragma unroll
                 for (int k = 0; k < kGrad / 4; ++k)
-                    u5[k] = row_sum(swap16_add(v10[2 * k], v10[2 * k + 1]));
+                    u5[k] = half_row_sum(swap16_add(v10[2 * k], v10[2 * k + 1]));
+                row_mirror_add5(u5[0], u5[1], u5[2], u5[3], u5[4]);
                 const int row = lane >> 4;
                 const int comp0 = ((row & 1) << 1) | (row >> 1);
                 if ((lane & 15) == 0) {
@@ -503,7 +516,7 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
             const float v = acc[k];
             if (v != 0.f) {
                 const int jj = k / kGrad, c = k - jj * kGrad;
-                atomicAdd(&dgeom[(size_t)ids[jj] * kGrad + c], v);
+                atomicAdd(&dgeom[(size_t)ids[jj] * kGrad + c], c < 6 ? -v : v);
             }
         }
     }
