@@ -186,6 +186,37 @@ int vings_splat_grad_finish(int N, const float* opacities, const float* scales,
                             float* g_xyz, float* g_rgb, float* g_opacity, float* g_scaling,
                             float* g_rotation, uint8_t* visible, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Forward-only importance of every splat in one view: importance[i] (+)= sum over pixels of
+ * the blend weight alpha*T, i.e. the value the backward pass leaves in scores.grad[:,0]
+ * (it does not depend on the upstream gradient).  Serves the scoring passes that the
+ * reference runs as render + backward of a throw-away loss: storage_control
+ * (gaussian_model.py:233-241) and calc_score_v1 (loop/loop_model.py:169-214).  Takes the
+ * outputs of vings_surfel_project / vings_surfel_bin; writes no image.
+ * accumulate = 0 zeroes importance[N] first.
+ */
+int vings_surfel_blend_importance(int N, int H, int W, const uint32_t* ranges,
+                                  const uint32_t* vals_sorted, const float* geom,
+                                  const uint8_t* pixel_mask, float* importance, int accumulate,
+                                  void* stream);
+
+/* ------------------------------------------------------------------------
+ * Pruning: order-preserving compaction of every per-splat array by a keep mask, in place of
+ * the array-by-array boolean indexing of prune_tensors_from_optimizer
+ * (gaussian_base.py:94-110) and update_records(mode="prune") (gaussian_model.py:178-183).
+ * plan : dst_index[i] = new row of splat i, or -1 if keep[i] == 0; *n_keep_host = rows kept
+ *        (synchronises once to return it: the caller sizes the destination arrays with it).
+ * apply: copies row i of each of the n_arrays source arrays (row_bytes_host[a] bytes per
+ *        row; pointer tables in HOST memory, at most 24 arrays) to row dst_index[i] of the
+ *        matching destination array.  Out of place.
+ */
+size_t vings_splat_compact_workspace_bytes(int N);
+int vings_splat_compact_plan(int N, const uint8_t* keep, int32_t* dst_index, void* workspace,
+                             size_t workspace_bytes, int64_t* n_keep_host, void* stream);
+int vings_splat_compact_apply(int N, const int32_t* dst_index, int n_arrays,
+                              const void* const* src_host, void* const* dst_host,
+                              const int* row_bytes_host, void* stream);
+
 /* Exchange between GPU replicas of the splat set (no counterpart in the reference, which is
  * single-GPU: configs/hierarchical/smallcity.yaml:11-13).  After vings_splat_grad_finish with
  * bookkeeping = 0, pack writes per splat one row of 16 floats {g_xyz 3, g_rgb 3, g_opacity,

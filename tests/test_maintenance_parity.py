@@ -1,0 +1,127 @@
+"""Map maintenance on the device (forward-only importance, stream compaction, pruning)
+against the CPU oracle / numpy.  Importance: 1e-4 relative L2 against the oracle's
+scores[:,0] (the backward pass' definition of the same quantity).  Compaction: bit-exact
+against numpy boolean indexing."""
+import numpy as np
+import pytest
+import torch
+
+from scenes import oracle_forward, scene
+from vings_mono_amd import harness, maintenance, surfel, synth
+import test_surfel_parity as TS
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("case", [dict(n=10000, W=640, H=480),
+                                  dict(n=4000, W=250, H=131, scale_mul=2.0),
+                                  dict(n=3000, W=200, H=120, scale_mul=0.05)])
+def test_importance_matches_backward_scores(case, oracle32):
+    dev = torch.device(DEV)
+    sc = scene(**case)
+    H, W = sc["H"], sc["W"]
+    ref_st = oracle_forward(oracle32, sc)
+    zc, za = np.zeros((3, H, W), np.float32), np.zeros((9, H, W), np.float32)
+    want = oracle32.backward(ref_st, zc, za)["scores"][:, 0]
+    inp = TS._dev_inputs(sc, dev)
+    got, radii = surfel.view_importance(inp["means3D"], inp["colors"], inp["opacities"],
+                                        inp["scales"], inp["rotations"], TS._settings(sc, dev))
+    got = got.cpu().numpy().astype(np.float64)
+    rel = np.sqrt(((got - want) ** 2).sum()) / np.sqrt((want.astype(np.float64) ** 2).sum())
+    assert rel <= 1e-4, rel
+    assert np.all(got[want == 0] == 0)
+    np.testing.assert_array_equal(radii.cpu().numpy(), ref_st["radii"])
+    # accumulate = True adds a second view on top
+    out = torch.from_numpy(got.astype(np.float32)).to(dev)
+    surfel.view_importance(inp["means3D"], inp["colors"], inp["opacities"], inp["scales"],
+                           inp["rotations"], TS._settings(sc, dev), out=out, accumulate=True)
+    np.testing.assert_allclose(out.cpu().numpy(), 2 * got, rtol=1e-5, atol=1e-6)
+
+
+def test_importance_honours_pixel_mask(oracle32):
+    dev = torch.device(DEV)
+    sc = scene(3000, 160, 96)
+    mask = np.random.default_rng(5).uniform(size=(96, 160)) > 0.4
+    ref_st = oracle_forward(oracle32, sc, pixel_mask=mask)
+    z = lambda c: np.zeros((c, 96, 160), np.float32)
+    want = oracle32.backward(ref_st, z(3), z(9))["scores"][:, 0]
+    inp = TS._dev_inputs(sc, dev)
+    got, _ = surfel.view_importance(inp["means3D"], inp["colors"], inp["opacities"], inp["scales"],
+                                    inp["rotations"], TS._settings(sc, dev, mask))
+    got = got.cpu().numpy().astype(np.float64)
+    assert np.sqrt(((got - want) ** 2).sum()) <= 1e-4 * np.sqrt((want.astype(np.float64) ** 2).sum())
+
+
+@pytest.mark.parametrize("n,frac", [(1, 1.0), (1, 0.0), (257, 0.5), (100000, 0.9), (4096, 0.0),
+                                    (5000, 1.0)])
+def test_compaction_is_bit_exact(n, frac):
+    rng = np.random.default_rng(n + int(frac * 10))
+    keep = rng.random(n) < frac
+    host = [rng.normal(size=(n, 3)).astype(np.float32), rng.normal(size=(n, 1)).astype(np.float32),
+            rng.normal(size=(n,)).astype(np.float32), rng.integers(-5, 1 << 40, n).astype(np.int64),
+            rng.random(n) < 0.5, rng.normal(size=(n, 4)).astype(np.float32),
+            rng.normal(size=(n, 2)).astype(np.float32), rng.integers(0, 255, (n, 3)).astype(np.uint8)]
+    outs, m = maintenance.compact([torch.from_numpy(a).to(DEV) for a in host],
+                                  torch.from_numpy(keep).to(DEV))
+    assert m == int(keep.sum())
+    for got, a in zip(outs, host):
+        np.testing.assert_array_equal(got.cpu().numpy(), a[keep])
+
+
+def test_prune_keeps_parameters_state_and_records():
+    dev = torch.device(DEV)
+    W, H = 160, 96
+    raw = synth.make_splats(4000, W, H, n_views=2, seed=8)
+    intr = synth.intrinsic_for(W, H)
+    w2c = torch.linalg.inv(synth.window_poses(2)[1]).to(dev)
+    gtp = {k: v.to(dev) for k, v in synth.perturb_splats(raw).items()}
+    with torch.no_grad():
+        pr = harness.render(gtp, w2c, intr)
+        gt = {"rgb": pr["rgb"].clone(), "depth": pr["depth"].clone(),
+              "depth_cov": torch.ones_like(pr["depth"])}
+    m = harness.SurfelMapper(raw, dev)
+    cam = harness.view_settings(w2c, intr)
+    m.fused_view(cam, intr, gt, w2c[:3, :3].cpu(), 0)          # creates Adam state and scores
+    before = {k: m.params[k].detach().clone() for k in m.NAMES}
+    mom = {k: m.optimizer.state[m.params[k]]["exp_avg"].clone() for k in m.NAMES}
+    glob = m.global_scores.clone()
+    prune_mask = torch.rand(m.n, device=dev) < 0.3
+    left = maintenance.prune(m, prune_mask)
+    keep = ~prune_mask
+    assert left == int(keep.sum()) == m.n
+    for k in m.NAMES:
+        assert torch.equal(m.params[k].detach(), before[k][keep])
+        assert torch.equal(m.optimizer.state[m.params[k]]["exp_avg"], mom[k][keep])
+        assert m.optimizer.state[m.params[k]]["exp_avg_sq"].shape == before[k][keep].shape
+    assert torch.equal(m.global_scores, glob[keep])
+    assert m.stable_mask.shape == (left,) and m.globalkf_id.shape == (left,)
+    loss = m.fused_view(cam, intr, gt, w2c[:3, :3].cpu(), 1)   # the pruned map still trains
+    assert torch.isfinite(loss).all()
+
+
+def test_storage_control_prunes_by_forward_importance():
+    dev = torch.device(DEV)
+    W, H = 160, 96
+    raw = synth.make_splats(6000, W, H, n_views=3, seed=4)
+    intr = synth.intrinsic_for(W, H)
+    w2cs = [torch.linalg.inv(p).to(dev) for p in synth.window_poses(3)]
+    m = harness.SurfelMapper(raw, dev)
+    m.stable_mask[::5] = True
+    # the reference's route: render + backward per keyframe, read scores.grad[:,0]
+    want = torch.zeros(m.n, device=dev)
+    for w2c in w2cs:
+        scores = torch.zeros((m.n, 2), device=dev, requires_grad=True)
+        rgb, _, _ = harness.render_raw(m.params, w2c, intr, scores=scores)
+        (rgb * 0).sum().backward()
+        want += scores.grad[:, 0]
+    got = maintenance.importance_over_views(m, w2cs, intr)
+    assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    expect = (want > 0.05) & (~m.stable_mask) & (want < 0.8)
+    n0 = m.n
+    mask = maintenance.storage_control(m, w2cs, intr)
+    # only splats whose score sits within rounding of a threshold may be classified differently
+    assert int((mask != expect).sum()) <= 2
+    assert m.n == n0 - int(mask.sum())
+    maintenance.stablemask_control(m)
+    assert float(m.local_scores.abs().max()) == 0.0

@@ -1,0 +1,149 @@
+// Stream compaction of the splat set on gfx950: every per-splat array (parameters, Adam
+// moments, score records) loses the rows of pruned splats in one plan + one apply launch,
+// order preserved.
+//
+// Replaces the boolean-mask indexing the reference runs array by array when it prunes
+//   prune_tensors_from_optimizer  /root/reference/scripts/gaussian/gaussian_base.py:94-110
+//   update_records(mode="prune")  /root/reference/scripts/gaussian/gaussian_model.py:178-183
+// (called from add_new_frame :121-123 and storage_control :246-248): 20 index_select-style
+// launches plus 20 mask scans there.
+#include "common.hpp"
+
+namespace vings {
+
+// keep[i] != 0 -> dst[i] = number of kept rows before i.  Block counts, a single-workgroup
+// scan over them, then the per-row offsets.
+__global__ __launch_bounds__(256) void compact_count_kernel(int N, const uint8_t* __restrict__ keep,
+                                                            uint32_t* __restrict__ block_counts) {
+    __shared__ uint32_t wsum[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t k = (i < N && keep[i]) ? 1u : 0u;
+    const uint32_t s = wave_sum_u32(k);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(1024) void compact_scan_kernel(uint32_t* __restrict__ counts, int nb) {
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < nb ? counts[i] : 0u;
+        const uint32_t inc = wave_scan_incl(v);
+        if (lane == 63) wtot[w] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int k = 0; k < w; ++k) woff += wtot[k];
+        const uint32_t carry = carry_s;
+        if (i < nb) counts[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[nb] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void compact_index_kernel(int N, const uint8_t* __restrict__ keep,
+                                                            const uint32_t* __restrict__ block_prefix,
+                                                            int32_t* __restrict__ dst) {
+    __shared__ uint32_t wtot[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t k = (i < N && keep[i]) ? 1u : 0u;
+    const uint32_t inc = wave_scan_incl(k);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    uint32_t off = block_prefix[blockIdx.x] + inc - k;
+    for (int q = 0; q < w; ++q) off += wtot[q];
+    if (i < N) dst[i] = k ? (int32_t)off : -1;
+}
+
+constexpr int kMaxArrays = 24;
+struct CompactArrays {
+    const char* src[kMaxArrays];
+    char* dst[kMaxArrays];
+    int row_bytes[kMaxArrays];
+    int n;
+};
+
+// One lane per source row; a kept row is copied in every array.  Rows are a few bytes
+// (4 .. 16), so 4-byte words when the row allows it, bytes otherwise.
+__global__ __launch_bounds__(256) void compact_apply_kernel(int N, const int32_t* __restrict__ dst_index,
+                                                            CompactArrays A) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int d = dst_index[i];
+    if (d < 0) return;
+    for (int a = 0; a < A.n; ++a) {
+        const int rb = A.row_bytes[a];
+        const char* s = A.src[a] + (size_t)i * rb;
+        char* t = A.dst[a] + (size_t)d * rb;
+        if ((rb & 3) == 0) {
+            for (int k = 0; k < rb; k += 4)
+                *reinterpret_cast<uint32_t*>(t + k) = *reinterpret_cast<const uint32_t*>(s + k);
+        } else {
+            for (int k = 0; k < rb; ++k) t[k] = s[k];
+        }
+    }
+}
+
+}  // namespace vings
+
+using namespace vings;
+
+extern "C" size_t vings_splat_compact_workspace_bytes(int N) {
+    return sizeof(uint32_t) * ((size_t)cdiv(N > 0 ? N : 1, 256) + 1);
+}
+
+extern "C" int vings_splat_compact_plan(int N, const uint8_t* keep, int32_t* dst_index,
+                                        void* workspace, size_t workspace_bytes,
+                                        int64_t* n_keep_host, void* stream) {
+    VINGS_REQUIRE(N >= 0 && n_keep_host, "sizes");
+    *n_keep_host = 0;
+    if (N == 0) return VINGS_OK;
+    VINGS_REQUIRE(keep && dst_index && workspace, "null pointer");
+    VINGS_REQUIRE(workspace_bytes >= vings_splat_compact_workspace_bytes(N), "workspace too small");
+    VINGS_REQUIRE(((uintptr_t)workspace & 3) == 0, "workspace must be 4-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t* counts = reinterpret_cast<uint32_t*>(workspace);
+    const int nb = cdiv(N, 256);
+    compact_count_kernel<<<nb, 256, 0, s>>>(N, keep, counts);
+    VINGS_LAUNCH_CHECK();
+    compact_scan_kernel<<<1, 1024, 0, s>>>(counts, nb);
+    VINGS_LAUNCH_CHECK();
+    compact_index_kernel<<<nb, 256, 0, s>>>(N, keep, counts, dst_index);
+    VINGS_LAUNCH_CHECK();
+    uint32_t total = 0;
+    VINGS_CHECK_HIP(hipMemcpyAsync(&total, counts + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    VINGS_CHECK_HIP(hipStreamSynchronize(s));
+    *n_keep_host = (int64_t)total;
+    return VINGS_OK;
+}
+
+extern "C" int vings_splat_compact_apply(int N, const int32_t* dst_index, int n_arrays,
+                                         const void* const* src_host, void* const* dst_host,
+                                         const int* row_bytes_host, void* stream) {
+    VINGS_REQUIRE(N >= 0 && n_arrays > 0 && n_arrays <= kMaxArrays, "1..24 arrays");
+    if (N == 0) return VINGS_OK;
+    VINGS_REQUIRE(dst_index && src_host && dst_host && row_bytes_host, "null pointer");
+    CompactArrays A;
+    A.n = n_arrays;
+    for (int a = 0; a < n_arrays; ++a) {
+        VINGS_REQUIRE(src_host[a] && dst_host[a] && row_bytes_host[a] > 0, "array pointers");
+        VINGS_REQUIRE(src_host[a] != dst_host[a], "compaction is out of place");
+        if ((row_bytes_host[a] & 3) == 0)
+            VINGS_REQUIRE((((uintptr_t)src_host[a] | (uintptr_t)dst_host[a]) & 3) == 0,
+                          "word rows must be 4-byte aligned");
+        A.src[a] = reinterpret_cast<const char*>(src_host[a]);
+        A.dst[a] = reinterpret_cast<char*>(dst_host[a]);
+        A.row_bytes[a] = row_bytes_host[a];
+    }
+    ProfScope prof(PROF_GLUE, (hipStream_t)stream);
+    compact_apply_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(N, dst_index, A);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}

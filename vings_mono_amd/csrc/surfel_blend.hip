@@ -324,20 +324,83 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(
     allmap[8 * HW + pix] = F1;
 }
 
-// ---------------------------------------------------------------------------
-// backward
-// ---------------------------------------------------------------------------
-
-// Sum over the 16 lanes of a DPP row; every lane of the row receives the total.
-// The last step is written as one fused v_add_f32_dpp: left to the compiler it is sunk
-// into the lane-0-only atomic region as v_mov 0 + v_mov_dpp + v_add (three issues).
-// The s_nop covers the two wait states a DPP read needs after a VALU write of its source.
+// Sum over each 8-lane half of a DPP row; every lane of the half receives it.
 __device__ __forceinline__ float half_row_sum(float v) {
     v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
     v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
     v += dpp_f<0x141>(v);  // row_half_mirror
     return v;
 }
+
+// Forward-only importance pass: importance[i] += sum over pixels of the blend weight
+// alpha * T of splat i in this view -- the value the backward pass leaves in
+// scores.grad[:,0], which does not depend on the upstream gradient.  The reference obtains
+// it by rendering and back-propagating a throw-away loss
+// (/root/reference/scripts/gaussian/gaussian_model.py:233-241,
+//  /root/reference/scripts/loop/loop_model.py:185-186); here no image is written and no
+// backward pass runs.  Same walk as blend_fwd_kernel; one wave sum per (wave, splat).
+__global__ __launch_bounds__(256) void blend_importance_kernel(
+    int H, int W, int gx, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ vals,
+    const float* __restrict__ geom, const uint8_t* __restrict__ pixel_mask,
+    float* __restrict__ importance) {
+    __shared__ float4 rec[kBatch * (kRec4 - 1)];
+    __shared__ unsigned long long hit[16];
+    __shared__ float acc[kBatch];
+    __shared__ uint32_t ids[kBatch];
+    const int tile = blockIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const int px = tx * 16 + kBlk * ((threadIdx.x >> 6) & 1) + (threadIdx.x & 7);
+    const int py = ty * 16 + kBlk * (threadIdx.x >> 7) + ((threadIdx.x >> 3) & 7);
+    const bool inside = px < W && py < H;
+    bool done = !inside || (pixel_mask && pixel_mask[(size_t)py * W + px] == 0);
+    const float fx = (float)px, fy = (float)py;
+    const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float T = 1.f;
+    for (uint32_t base = r0; base < r1; base += kBatch) {
+        if (__syncthreads_and(done)) break;   // also orders the previous flush before restaging
+        stage_batch(rec, hit, geom, vals, base + threadIdx.x, r1, ids, (float)(tx * 16),
+                    (float)(ty * 16));
+        acc[threadIdx.x] = 0.f;
+        __syncthreads();
+        HitWalk walk;
+        walk.begin_forward(hit, wv);
+        int j;
+        while (walk.next_forward(j)) {
+            if (__ballot(!done) == 0ull) break;
+            const Splat s = unpack(load_rec(rec + j * (kRec4 - 1)));
+            Hit h;
+            bool c = eval_hit(s, fx, fy, h) & !done;
+            const float test_T = T * (1.f - h.alpha);
+            const bool sat = c & (test_T < kTMin);
+            done |= sat;
+            c &= !sat;
+            if (__ballot(c) == 0ull) continue;
+            float w = c ? h.alpha * T : 0.f;
+            T = c ? test_T : T;
+            w = half_row_sum(w);
+            w += dpp_f<0x140>(w);          // row_mirror: sum of the 16-lane row
+            w = swap16_add(w, w);
+            w = swap32_add(w, w);
+            if (lane == 0) atomicAdd(&acc[j], w);
+        }
+        __syncthreads();
+        const uint32_t n = min((uint32_t)kBatch, r1 - base);
+        if (threadIdx.x < n) {
+            const float v = acc[threadIdx.x];
+            if (v != 0.f) atomicAdd(&importance[ids[threadIdx.x]], v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------
+
+// Last step of the sum over the 16 lanes of a DPP row, for five registers at once, written
+// as fused v_add_f32_dpp: left to the compiler it is sunk into the lane-0-only atomic region
+// as v_mov 0 + v_mov_dpp + v_add (three issues each).  The s_nop covers the two wait states
+// a DPP read needs after a VALU write of its source.
 __device__ __forceinline__ void row_mirror_add5(float& a, float& b, float& c, float& d, float& e) {
     asm volatile(
         "s_nop 1\n\t"
@@ -558,6 +621,24 @@ extern "C" int vings_surfel_blend_backward(int N, int H, int W, const uint32_t* 
     ProfScope prof(PROF_BLEND_BWD, s);
     blend_bwd_kernel<<<gx * gy, 256, 0, s>>>(H, W, gx, ranges, vals_sorted, geom, bg, pixel_mask,
                                              final_T, n_contrib, dL_dcolor, dL_dallmap, dgeom);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}
+
+extern "C" int vings_surfel_blend_importance(int N, int H, int W, const uint32_t* ranges,
+                                             const uint32_t* vals_sorted, const float* geom,
+                                             const uint8_t* pixel_mask, float* importance,
+                                             int accumulate, void* stream) {
+    VINGS_REQUIRE(N >= 0 && H > 0 && W > 0, "sizes");
+    if (N == 0) return VINGS_OK;
+    VINGS_REQUIRE(ranges && importance, "null pointer");
+    VINGS_REQUIRE(((uintptr_t)geom & 15) == 0, "geom must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) VINGS_CHECK_HIP(hipMemsetAsync(importance, 0, sizeof(float) * (size_t)N, s));
+    const int gx = (W + 15) / 16, gy = (H + 15) / 16;
+    ProfScope prof(PROF_BLEND_FWD, s);
+    blend_importance_kernel<<<gx * gy, 256, 0, s>>>(H, W, gx, ranges, vals_sorted, geom,
+                                                    pixel_mask, importance);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }

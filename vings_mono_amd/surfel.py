@@ -56,7 +56,30 @@ class SurfelForwardState:
 
 
 def rasterize_forward(means3D, colors, opacities, scales, rotations, settings, keep_keys=False):
-    """Run projection -> binning -> blend. Returns a SurfelForwardState."""
+    """Run projection -> binning -> blend. Returns (SurfelForwardState, aux)."""
+    return _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys, True)
+
+
+def view_importance(means3D, colors, opacities, scales, rotations, settings, out=None,
+                    accumulate=False):
+    """Per-splat blend weight mass sum(alpha*T) of one view without rendering an image or
+    running a backward pass (= scores.grad[:,0] of the reference's render + backward,
+    gaussian_model.py:233-241).  Returns (importance[N], radii[N])."""
+    L = _lib.lib()
+    st, aux = _forward(means3D, colors, opacities, scales, rotations, settings, False, False)
+    N = st.N
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=means3D.device)
+        accumulate = False
+    mask = aux[3]
+    check(L.vings_surfel_blend_importance(N, st.H, st.W, ptr(st.ranges), ptr(st.vals), ptr(st.geom),
+                                          ptr(mask), ptr(out), 1 if accumulate else 0,
+                                          stream_ptr(means3D.device)),
+          "vings_surfel_blend_importance")
+    return out, st.radii
+
+
+def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys, blend):
     L = _lib.lib()
     dev = means3D.device
     N = means3D.shape[0]
@@ -107,6 +130,9 @@ def rasterize_forward(means3D, colors, opacities, scales, rotations, settings, k
                              ptr(st.rect), ptr(st.tiles_touched),
                              ptr(st.block_prefix), ptr(st.keys), ptr(st.vals), ptr(st.ranges),
                              ws_ptr, ws_bytes, stream), "vings_surfel_bin")
+    if not blend:
+        st.keys = None
+        return st, (view, proj, bg, mask, flow)
     st.color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
     st.allmap = torch.empty((AUX_CHANNELS, H, W), dtype=torch.float32, device=dev)
     st.final_T = torch.empty((3, H, W), dtype=torch.float32, device=dev)
