@@ -89,16 +89,21 @@ def main():
     W, H, V = args.width, args.height, args.views
     intr = synth.intrinsic_for(W, H)
     n_views_total = V * world
-    # identical splat replica on every rank; each rank owns V views of the window
-    raw = synth.make_splats(args.splats, W, H, n_views=n_views_total, seed=synth.SEED_BASE)
+    # Identical splat replica on every rank, filling the frustum union of ONE V-keyframe
+    # window.  Every rank films that window from its own height (5 cm apart), so all ranks
+    # see the same share of the map: the work per GPU stays what it is at N = 1 (weak
+    # scaling) instead of thinning out as the window would stretch over more keyframes.
+    raw = synth.make_splats(args.splats, W, H, n_views=V, seed=synth.SEED_BASE)
     mapper = harness.SurfelMapper(raw, dev)
     gt_mapper_params = {k: v.to(dev) for k, v in synth.perturb_splats(raw).items()}
-    c2w_all = synth.window_poses(n_views_total).to(dev)
-    my_views = list(range(rank * V, (rank + 1) * V))
+    c2w_rank = synth.window_poses(V)
+    c2w_rank[:, 1, 3] += 0.05 * rank
+    c2w_rank = c2w_rank.to(dev)
+    my_views = list(range(rank * V, (rank + 1) * V))      # global keyframe ids
     gts = []
     with torch.no_grad():
-        for k in my_views:
-            pred = harness.render(gt_mapper_params, torch.linalg.inv(c2w_all[k]), intr)
+        for i in range(V):
+            pred = harness.render(gt_mapper_params, torch.linalg.inv(c2w_rank[i]), intr)
             depth = pred["depth"].clone()
             gts.append({"rgb": pred["rgb"].clone(), "depth": depth,
                         "depth_cov": torch.ones_like(depth)})
@@ -113,7 +118,7 @@ def main():
 
     # keyframe poses are inputs of the mapper: their inverses (device) and the rotation block
     # the loss kernels take from the host are prepared once, like the ground-truth maps
-    w2c_dev = [torch.linalg.inv(c2w_all[k]) for k in my_views]
+    w2c_dev = [torch.linalg.inv(c2w_rank[i]) for i in range(V)]
     R_host = [w[:3, :3].cpu() for w in w2c_dev]
     cams = [harness.view_settings(w, intr) for w in w2c_dev]
 
