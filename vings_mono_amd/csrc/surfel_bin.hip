@@ -63,23 +63,6 @@ __device__ __forceinline__ uint32_t digit_of(uint64_t k, int shift) {
     return (uint32_t)(k >> shift) & (kRadix - 1);
 }
 
-// Global digit histograms of every pass in one read of the keys:
-// ghist[pass][256].
-__global__ __launch_bounds__(256) void sort_global_hist_kernel(
-    const uint64_t* __restrict__ keys, int64_t D, int passes, uint32_t* __restrict__ ghist) {
-    __shared__ uint32_t h[kMaxPasses * kRadix];
-    for (int k = threadIdx.x; k < passes * kRadix; k += 256) h[k] = 0;
-    __syncthreads();
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < D; i += stride) {
-        const uint64_t k = keys[i];
-        for (int p = 0; p < passes; ++p) atomicAdd(&h[p * kRadix + digit_of(k, p * kRadixBits)], 1u);
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < passes * kRadix; k += 256)
-        if (h[k]) atomicAdd(&ghist[k], h[k]);
-}
-
 // Per-tile digit histogram of one pass: thist[digit][tile].
 __global__ __launch_bounds__(kSortThreads) void sort_tile_hist_kernel(
     const uint64_t* __restrict__ keys, int64_t D, int shift, int ntiles,
@@ -97,21 +80,18 @@ __global__ __launch_bounds__(kSortThreads) void sort_tile_hist_kernel(
     thist[(size_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
-// One 256-lane workgroup per digit: exclusive scan of that digit's row of thist, offset
-// by the number of keys with a smaller digit (from the global histogram).  Each lane owns
-// 8 consecutive entries, so rows of up to 2048 sort tiles (4 M keys) take one round.
+// One 256-lane workgroup per digit: exclusive scan of that digit's row of thist (per sort
+// tile: keys with this digit in earlier tiles) and the row total into totals[digit]; the
+// scatter adds the number of keys with a smaller digit itself.  Each lane owns 8 consecutive
+// entries, so rows of up to 2048 sort tiles (4 M keys) take one round.
 constexpr int kScanItems = 8;
 __global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t* __restrict__ thist, int ntiles,
-                                                        const uint32_t* __restrict__ ghist_pass) {
+                                                        uint32_t* __restrict__ totals) {
     __shared__ uint32_t wtot[4];
     __shared__ uint32_t carry_s;
     const int digit = blockIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t base = threadIdx.x < digit ? ghist_pass[threadIdx.x] : 0u;   // digit <= 255
-    base = wave_sum_u32(base);
-    if (lane == 0) wtot[w] = base;
-    __syncthreads();
-    if (threadIdx.x == 0) carry_s = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     uint32_t* row = thist + (size_t)digit * ntiles;
     for (int t0 = 0; t0 < ntiles; t0 += 256 * kScanItems) {
@@ -136,6 +116,7 @@ __global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t* __restrict__ t
         if (threadIdx.x == 255) carry_s = run;
         __syncthreads();
     }
+    if (threadIdx.x == 0) totals[digit] = carry_s;
 }
 
 // Stable scatter of one tile.  Keys are held in a wave-striped arrangement
@@ -146,12 +127,22 @@ __global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t* __restrict__ t
 __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(
     const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t D, int shift,
-    int ntiles, const uint32_t* __restrict__ thist) {
+    int ntiles, const uint32_t* __restrict__ thist, const uint32_t* __restrict__ totals) {
     __shared__ uint32_t wcount[4][kRadix];  // per-wave digit counts, then prefixes
     __shared__ uint32_t gbase[kRadix];
+    __shared__ uint32_t wsum4[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int k = threadIdx.x; k < 4 * kRadix; k += kSortThreads) (&wcount[0][0])[k] = 0;
-    gbase[threadIdx.x] = thist[(size_t)threadIdx.x * ntiles + blockIdx.x];
+    // first output slot of digit d in this tile = keys with a smaller digit anywhere
+    // (exclusive prefix of the 256 digit totals, one digit per lane) + keys with digit d in
+    // earlier tiles
+    const uint32_t tot = totals[threadIdx.x];
+    const uint32_t inc = wave_scan_incl(tot);
+    if (lane == 63) wsum4[w] = inc;
+    __syncthreads();
+    uint32_t below = inc - tot;
+    for (int k = 0; k < w; ++k) below += wsum4[k];
+    gbase[threadIdx.x] = below + thist[(size_t)threadIdx.x * ntiles + blockIdx.x];
     __syncthreads();
 
     const int64_t wbase = (int64_t)blockIdx.x * kSortTile + w * (kSortItems * 64);
@@ -236,7 +227,7 @@ static int sort_passes(int T, int low_bits) {
 struct BinWorkspace {
     uint64_t* keys_alt;
     uint32_t* vals_alt;
-    uint32_t* ghist;  // [kMaxPasses][256]
+    uint32_t* ghist;  // [256] digit totals of the current pass
     uint32_t* thist;  // [256][ntiles]
     size_t bytes;
 };
@@ -305,19 +296,15 @@ extern "C" int vings_surfel_bin(int N, int H, int W, int64_t D, uint32_t depth_b
     VINGS_LAUNCH_CHECK();
 
     const int ntiles = cdiv(D, kSortTile);
-    VINGS_CHECK_HIP(hipMemsetAsync(b.ghist, 0, sizeof(uint32_t) * kMaxPasses * kRadix, s));
-    const int hist_blocks = ntiles < 2048 ? ntiles : 2048;
-    sort_global_hist_kernel<<<hist_blocks, 256, 0, s>>>(kbuf[cur], D, passes, b.ghist);
-    VINGS_LAUNCH_CHECK();
     for (int p = 0; p < passes; ++p) {
         const int shift = p * kRadixBits;
         sort_tile_hist_kernel<<<ntiles, kSortThreads, 0, s>>>(kbuf[cur], D, shift, ntiles, b.thist);
         VINGS_LAUNCH_CHECK();
-        sort_scan_kernel<<<kRadix, 256, 0, s>>>(b.thist, ntiles, b.ghist + p * kRadix);
+        sort_scan_kernel<<<kRadix, 256, 0, s>>>(b.thist, ntiles, b.ghist);
         VINGS_LAUNCH_CHECK();
         sort_scatter_kernel<<<ntiles, kSortThreads, 0, s>>>(kbuf[cur], vbuf[vcur], kbuf[cur ^ 1],
                                                             vbuf[vcur ^ 1], D, shift, ntiles,
-                                                            b.thist);
+                                                            b.thist, b.ghist);
         VINGS_LAUNCH_CHECK();
         cur ^= 1;
         vcur ^= 1;
