@@ -193,12 +193,14 @@ int vings_splat_grad_finish(int N, const float* opacities, const float* scales,
  * reference runs as render + backward of a throw-away loss: storage_control
  * (gaussian_model.py:233-241) and calc_score_v1 (loop/loop_model.py:169-214).  Takes the
  * outputs of vings_surfel_project / vings_surfel_bin; writes no image.
- * accumulate = 0 zeroes importance[N] first.
+ * accumulate = 0 zeroes importance[N] first.  rgb_max (device float, may be NULL; needs bg[3])
+ * receives max(0, largest value of the colour image this view would render), which
+ * calc_score_v1 tests against 0.1 to skip empty views (loop_model.py:181).
  */
 int vings_surfel_blend_importance(int N, int H, int W, const uint32_t* ranges,
                                   const uint32_t* vals_sorted, const float* geom,
                                   const uint8_t* pixel_mask, float* importance, int accumulate,
-                                  void* stream);
+                                  const float* bg, float* rgb_max, void* stream);
 
 /* ------------------------------------------------------------------------
  * Pruning: order-preserving compaction of every per-splat array by a keep mask, in place of
@@ -216,6 +218,26 @@ int vings_splat_compact_plan(int N, const uint8_t* keep, int32_t* dst_index, voi
 int vings_splat_compact_apply(int N, const int32_t* dst_index, int n_arrays,
                               const void* const* src_host, void* const* dst_host,
                               const int* row_bytes_host, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Loop closure, per-splat stages.
+ * top3_update: folds the importance of one more keyframe view into every splat's record of
+ *   its three best keyframes, scores3[N,3] (descending) and kfids3[N,3] (int32), with the
+ *   comparisons of calc_score_v1 (loop/loop_model.py:190-211; strict, so ties insert nothing).
+ * reanchor: for every splat whose owning keyframe owner_kf[i*owner_stride] lies in
+ *   [kf_start, kf_end]: xyz <- new_c2w[kf] * (scale[kf] * (old_w2c[kf] * xyz)), rotation <-
+ *   delta_quat[kf] * rotation / |rotation| (loop/loop_rectify.py:322-367), in place.
+ *   Pose tables are device arrays indexed by keyframe: old_w2c, new_c2w [K,12] (3x4 row
+ *   major), delta_quat [K,4] (w,x,y,z; the rotation of new_c2w * old_w2c), scale [K].
+ *   Quaternions are (w,x,y,z) throughout, as the rasteriser reads them; the reference
+ *   round-trips this step through (x,y,z,w) libraries -- flagged, not reproduced.
+ */
+int vings_splat_top3_update(int N, const float* cur_importance, int kf_id, float* scores3,
+                            int32_t* kfids3, void* stream);
+int vings_splat_reanchor(int N, float* xyz, float* rotation, const int32_t* owner_kf,
+                         int owner_stride, int kf_start, int kf_end, int K, const float* old_w2c,
+                         const float* new_c2w, const float* delta_quat, const float* scale,
+                         void* stream);
 
 /* Exchange between GPU replicas of the splat set (no counterpart in the reference, which is
  * single-GPU: configs/hierarchical/smallcity.yaml:11-13).  After vings_splat_grad_finish with

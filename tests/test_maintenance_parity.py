@@ -100,6 +100,73 @@ def test_prune_keeps_parameters_state_and_records():
     assert torch.isfinite(loss).all()
 
 
+def test_top3_update_matches_reference_logic():
+    from oracle import mapper_oracle as mo
+    from vings_mono_amd import _lib
+    L = _lib.lib()
+    n = 5000
+    rng = np.random.default_rng(2)
+    s = np.zeros((n, 3), np.float32)
+    k = np.zeros((n, 3), np.int32)
+    ts, tk = torch.from_numpy(s).to(DEV), torch.from_numpy(k).to(DEV)
+    for kf in range(7):
+        cur = (rng.random(n) * (rng.random(n) > 0.3)).astype(np.float32)
+        cur[: n // 50] = 0.25                       # repeated value: ties must not insert
+        s, k = mo.top3_update(s, k, cur, kf + 10)
+        tc = torch.from_numpy(cur).to(DEV)
+        _lib.check(L.vings_splat_top3_update(n, _lib.ptr(tc), kf + 10, _lib.ptr(ts), _lib.ptr(tk),
+                                             _lib.stream_ptr(torch.device(DEV))), "top3")
+    np.testing.assert_array_equal(ts.cpu().numpy(), s)
+    np.testing.assert_array_equal(tk.cpu().numpy(), k)
+
+
+def test_calc_score_and_rectify_gaussians():
+    from oracle import mapper_oracle as mo
+    dev = torch.device(DEV)
+    W, H, K = 160, 96, 4
+    raw = synth.make_splats(6000, W, H, n_views=K, seed=12)
+    intr = synth.intrinsic_for(W, H)
+    c2ws = synth.window_poses(K)
+    m = harness.SurfelMapper(raw, dev)
+    scores3, ids3 = maintenance.calc_score(m, [c2ws[k] for k in range(K)], list(range(K)), intr)
+    # per-view importance through the backward route, then the oracle's top-3 bookkeeping
+    s = np.zeros((m.n, 3), np.float32)
+    ids = np.zeros((m.n, 3), np.int32)
+    for k in range(K):
+        sc = torch.zeros((m.n, 2), device=dev, requires_grad=True)
+        rgb, _, _ = harness.render_raw(m.params, torch.linalg.inv(c2ws[k]).to(dev), intr, scores=sc)
+        (rgb * 0).sum().backward()
+        s, ids = mo.top3_update(s, ids, sc.grad[:, 0].cpu().numpy(), k)
+    got_s, got_i = scores3.cpu().numpy(), ids3.cpu().numpy()
+    np.testing.assert_allclose(got_s, s, rtol=1e-4, atol=1e-5)     # float32 sums, two orders
+    assert (got_i == ids).mean() >= 0.999          # near-ties between views may swap
+
+    # re-anchor: a drifted loop over keyframes 1..2 with per-keyframe scales
+    new_c2ws = c2ws.clone()
+    a = np.radians(3.0)
+    Rz = torch.tensor([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]],
+                      dtype=torch.float32)
+    for k in (1, 2):
+        new_c2ws[k, :3, :3] = Rz @ c2ws[k, :3, :3]
+        new_c2ws[k, :3, 3] += torch.tensor([0.3, -0.1, 0.2]) * k
+    scales = torch.tensor([1.05, 0.97])
+    xyz0 = m.params["_xyz"].detach().cpu().numpy()
+    rot0 = m.params["_rotation"].detach().cpu().numpy()
+    want_xyz, want_R = mo.reanchor(xyz0, rot0, got_i[:, 0], 1, 2, c2ws.numpy(), new_c2ws.numpy(),
+                                   scales.numpy())
+    keep = got_s[:, 0] >= 0.1
+    n0 = m.n
+    deleted = maintenance.rectify_gaussians(m, c2ws, new_c2ws, scales, 1, 2, scores3, ids3)
+    assert np.array_equal(deleted.cpu().numpy(), ~keep) and m.n == int(keep.sum()) < n0
+    got_xyz = m.params["_xyz"].detach().cpu().numpy()
+    got_R = mo.quat_to_matrix_wxyz(m.params["_rotation"].detach().cpu().numpy().astype(np.float64))
+    np.testing.assert_allclose(got_xyz, want_xyz[keep], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(got_R, want_R[keep], atol=5e-6)
+    moved = ((got_i[:, 0] >= 1) & (got_i[:, 0] <= 2))[keep]
+    assert moved.any() and not moved.all()
+    assert np.array_equal(got_xyz[~moved], xyz0[keep][~moved])      # others untouched
+
+
 def test_storage_control_prunes_by_forward_importance():
     dev = torch.device(DEV)
     W, H = 160, 96

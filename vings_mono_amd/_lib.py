@@ -33,11 +33,13 @@ _SIGNATURES = {
     "vings_splat_activate": (_c.c_int, [_c.c_int] + [_P] * 7),
     "vings_splat_grad_finish": (_c.c_int, [_c.c_int] + [_P] * 15 + [_c.c_int64, _c.c_int] + [_P] * 7),
     "vings_surfel_blend_importance": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int] + [_P] * 5 +
-                                      [_c.c_int, _P]),
+                                      [_c.c_int, _P, _P, _P]),
     "vings_splat_compact_workspace_bytes": (_c.c_size_t, [_c.c_int]),
     "vings_splat_compact_plan": (_c.c_int, [_c.c_int, _P, _P, _P, _c.c_size_t,
                                             _c.POINTER(_c.c_int64), _P]),
     "vings_splat_compact_apply": (_c.c_int, [_c.c_int, _P, _c.c_int, _P, _P, _P, _P]),
+    "vings_splat_top3_update": (_c.c_int, [_c.c_int, _P, _c.c_int, _P, _P, _P]),
+    "vings_splat_reanchor": (_c.c_int, [_c.c_int, _P, _P, _P] + [_c.c_int] * 4 + [_P] * 5),
     "vings_splat_pack_exchange": (_c.c_int, [_c.c_int] + [_P] * 7 + [_c.c_int64] + [_P] * 3),
     "vings_splat_unpack_exchange": (_c.c_int, [_c.c_int] + [_P] * 13),
     "vings_mapping_loss_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int]),

@@ -1,0 +1,97 @@
+// Per-splat stages of loop closure on gfx950 (one lane per splat, HBM-bound):
+//  * top-3 keyframe record of every splat, updated with the importance of one more view
+//    (calc_score_v1, /root/reference/scripts/loop/loop_model.py:169-214);
+//  * rigid re-anchoring of the splats owned by the keyframes of the closed loop: position
+//    through the old camera frame, scaled, out through the rectified pose; orientation by the
+//    pose change (rectify_gaussians, /root/reference/scripts/loop/loop_rectify.py:322-367).
+// The importance itself comes from vings_surfel_blend_importance, the deletion of weak
+// splats (loop_rectify.py:325,370-380) from vings_splat_compact_*.
+#include "common.hpp"
+
+namespace vings {
+
+__global__ __launch_bounds__(256) void splat_top3_update_kernel(int N, const float* __restrict__ cur,
+                                                                int kf, float* __restrict__ scores3,
+                                                                int32_t* __restrict__ ids3) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float c = cur[i];
+    float s0 = scores3[3 * i], s1 = scores3[3 * i + 1], s2 = scores3[3 * i + 2];
+    int k0 = ids3[3 * i], k1 = ids3[3 * i + 1], k2 = ids3[3 * i + 2];
+    // the three masks are taken from the record as it was, then applied in order
+    const bool first = s0 < c;
+    const bool second = (s0 > c) && (s1 < c);
+    const bool third = (s1 > c) && (s2 < c);
+    if (first) { s2 = s1; s1 = s0; s0 = c; k2 = k1; k1 = k0; k0 = kf; }
+    if (second) { s2 = s1; s1 = c; k2 = k1; k1 = kf; }
+    if (third) { s2 = c; k2 = kf; }
+    if (first || second || third) {
+        scores3[3 * i] = s0; scores3[3 * i + 1] = s1; scores3[3 * i + 2] = s2;
+        ids3[3 * i] = k0; ids3[3 * i + 1] = k1; ids3[3 * i + 2] = k2;
+    }
+}
+
+// pose tables: old_w2c, new_c2w [K,12] (3x4 row major), dq [K,4] (w,x,y,z) = rotation of
+// new_c2w * old_w2c, scale [K]
+__global__ __launch_bounds__(256) void splat_reanchor_kernel(
+    int N, float* __restrict__ xyz, float* __restrict__ rot, const int32_t* __restrict__ owner,
+    int owner_stride, int kf_start, int kf_end, int K, const float* __restrict__ old_w2c,
+    const float* __restrict__ new_c2w, const float* __restrict__ dq,
+    const float* __restrict__ scale) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int kf = owner[(size_t)i * owner_stride];
+    if (kf < kf_start || kf > kf_end || kf < 0 || kf >= K) return;
+    const float* A = old_w2c + 12 * kf;
+    const float* B = new_c2w + 12 * kf;
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    const float s = scale[kf];
+    const float cx = (A[0] * x + A[1] * y + A[2] * z + A[3]) * s;
+    const float cy = (A[4] * x + A[5] * y + A[6] * z + A[7]) * s;
+    const float cz = (A[8] * x + A[9] * y + A[10] * z + A[11]) * s;
+    xyz[3 * i] = B[0] * cx + B[1] * cy + B[2] * cz + B[3];
+    xyz[3 * i + 1] = B[4] * cx + B[5] * cy + B[6] * cz + B[7];
+    xyz[3 * i + 2] = B[8] * cx + B[9] * cy + B[10] * cz + B[11];
+    // q' = dq * q / |q| (Hamilton product, w first); stored unit-length like the reference's
+    // conversion back from a rotation matrix
+    const float4 q = reinterpret_cast<const float4*>(rot)[i];   // w, x, y, z
+    const float inv = 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+    const float qw = q.x * inv, qx = q.y * inv, qy = q.z * inv, qz = q.w * inv;
+    const float dw = dq[4 * kf], dx = dq[4 * kf + 1], dy = dq[4 * kf + 2], dz = dq[4 * kf + 3];
+    reinterpret_cast<float4*>(rot)[i] =
+        make_float4(dw * qw - dx * qx - dy * qy - dz * qz, dw * qx + dx * qw + dy * qz - dz * qy,
+                    dw * qy - dx * qz + dy * qw + dz * qx, dw * qz + dx * qy - dy * qx + dz * qw);
+}
+
+}  // namespace vings
+
+using namespace vings;
+
+extern "C" int vings_splat_top3_update(int N, const float* cur_importance, int kf_id,
+                                       float* scores3, int32_t* kfids3, void* stream) {
+    VINGS_REQUIRE(N >= 0, "sizes");
+    if (N == 0) return VINGS_OK;
+    VINGS_REQUIRE(cur_importance && scores3 && kfids3, "null pointer");
+    ProfScope prof(PROF_GLUE, (hipStream_t)stream);
+    splat_top3_update_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(N, cur_importance, kf_id,
+                                                                            scores3, kfids3);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}
+
+extern "C" int vings_splat_reanchor(int N, float* xyz, float* rotation, const int32_t* owner_kf,
+                                    int owner_stride, int kf_start, int kf_end, int K,
+                                    const float* old_w2c, const float* new_c2w,
+                                    const float* delta_quat, const float* scale, void* stream) {
+    VINGS_REQUIRE(N >= 0 && K > 0 && owner_stride > 0 && kf_start <= kf_end, "sizes");
+    if (N == 0) return VINGS_OK;
+    VINGS_REQUIRE(xyz && rotation && owner_kf && old_w2c && new_c2w && delta_quat && scale,
+                  "null pointer");
+    VINGS_REQUIRE(((uintptr_t)rotation & 15) == 0, "rotation must be 16-byte aligned");
+    ProfScope prof(PROF_GLUE, (hipStream_t)stream);
+    splat_reanchor_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(
+        N, xyz, rotation, owner_kf, owner_stride, kf_start, kf_end, K, old_w2c, new_c2w,
+        delta_quat, scale);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}

@@ -342,21 +342,24 @@ __device__ __forceinline__ float half_row_sum(float v) {
 __global__ __launch_bounds__(256) void blend_importance_kernel(
     int H, int W, int gx, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ vals,
     const float* __restrict__ geom, const uint8_t* __restrict__ pixel_mask,
-    float* __restrict__ importance) {
+    float* __restrict__ importance, const float* __restrict__ bg,
+    uint32_t* __restrict__ rgb_max_bits) {
     __shared__ float4 rec[kBatch * (kRec4 - 1)];
     __shared__ unsigned long long hit[16];
     __shared__ float acc[kBatch];
     __shared__ uint32_t ids[kBatch];
+    __shared__ uint32_t wmaxs[4];
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
     const int px = tx * 16 + kBlk * ((threadIdx.x >> 6) & 1) + (threadIdx.x & 7);
     const int py = ty * 16 + kBlk * (threadIdx.x >> 7) + ((threadIdx.x >> 3) & 7);
     const bool inside = px < W && py < H;
-    bool done = !inside || (pixel_mask && pixel_mask[(size_t)py * W + px] == 0);
+    const bool masked = inside && pixel_mask && pixel_mask[(size_t)py * W + px] == 0;
+    bool done = !inside || masked;
     const float fx = (float)px, fy = (float)py;
     const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float T = 1.f;
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     for (uint32_t base = r0; base < r1; base += kBatch) {
         if (__syncthreads_and(done)) break;   // also orders the previous flush before restaging
         stage_batch(rec, hit, geom, vals, base + threadIdx.x, r1, ids, (float)(tx * 16),
@@ -378,6 +381,7 @@ __global__ __launch_bounds__(256) void blend_importance_kernel(
             if (__ballot(c) == 0ull) continue;
             float w = c ? h.alpha * T : 0.f;
             T = c ? test_T : T;
+            if (rgb_max_bits) { C0 += s.rgb[0] * w; C1 += s.rgb[1] * w; C2 += s.rgb[2] * w; }
             w = half_row_sum(w);
             w += dpp_f<0x140>(w);          // row_mirror: sum of the 16-lane row
             w = swap16_add(w, w);
@@ -389,6 +393,24 @@ __global__ __launch_bounds__(256) void blend_importance_kernel(
         if (threadIdx.x < n) {
             const float v = acc[threadIdx.x];
             if (v != 0.f) atomicAdd(&importance[ids[threadIdx.x]], v);
+        }
+    }
+    if (rgb_max_bits) {
+        // largest colour value of the image this view would render (the reference skips views
+        // whose render stays below 0.1); non-negative floats order like their bit patterns
+        float m = 0.f;
+        if (inside) {
+            const float Tb = masked ? 1.f : T;
+            m = fmaxf(fmaxf(C0 + Tb * bg[0], C1 + Tb * bg[1]), fmaxf(C2 + Tb * bg[2], 0.f));
+        }
+        uint32_t mb = __float_as_uint(m);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) mb = max(mb, (uint32_t)__shfl_xor(mb, o, 64));
+        if (lane == 0) wmaxs[wv] = mb;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            mb = max(max(wmaxs[0], wmaxs[1]), max(wmaxs[2], wmaxs[3]));
+            if (mb) atomicMax(rgb_max_bits, mb);
         }
     }
 }
@@ -628,17 +650,21 @@ extern "C" int vings_surfel_blend_backward(int N, int H, int W, const uint32_t* 
 extern "C" int vings_surfel_blend_importance(int N, int H, int W, const uint32_t* ranges,
                                              const uint32_t* vals_sorted, const float* geom,
                                              const uint8_t* pixel_mask, float* importance,
-                                             int accumulate, void* stream) {
+                                             int accumulate, const float* bg, float* rgb_max,
+                                             void* stream) {
     VINGS_REQUIRE(N >= 0 && H > 0 && W > 0, "sizes");
     if (N == 0) return VINGS_OK;
     VINGS_REQUIRE(ranges && importance, "null pointer");
     VINGS_REQUIRE(((uintptr_t)geom & 15) == 0, "geom must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    VINGS_REQUIRE(!rgb_max || bg, "rgb_max needs the background colour");
     if (!accumulate) VINGS_CHECK_HIP(hipMemsetAsync(importance, 0, sizeof(float) * (size_t)N, s));
+    if (rgb_max) VINGS_CHECK_HIP(hipMemsetAsync(rgb_max, 0, sizeof(float), s));
     const int gx = (W + 15) / 16, gy = (H + 15) / 16;
     ProfScope prof(PROF_BLEND_FWD, s);
     blend_importance_kernel<<<gx * gy, 256, 0, s>>>(H, W, gx, ranges, vals_sorted, geom,
-                                                    pixel_mask, importance);
+                                                    pixel_mask, importance, bg,
+                                                    reinterpret_cast<uint32_t*>(rgb_max));
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }

@@ -111,6 +111,91 @@ def storage_control(mapper, w2c_list, intr, low=0.05, high=0.8):
     return mask
 
 
+def calc_score(mapper, c2w_list, kf_ids, intr):
+    """Top-3 keyframes of every splat by blend-weight mass (loop_model.py:169-214): returns
+    (scores [N,3] descending, kf ids [N,3] int32).  One forward-only importance pass per
+    keyframe; a view whose render would stay below 0.1 everywhere is skipped like there."""
+    from .harness import view_settings
+    L = _lib.lib()
+    dev, n = mapper.device, mapper.n
+    scores3 = torch.zeros((n, 3), dtype=torch.float32, device=dev)
+    ids3 = torch.zeros((n, 3), dtype=torch.int32, device=dev)
+    cur = torch.empty(n, dtype=torch.float32, device=dev)
+    rgb_max = torch.zeros(1, dtype=torch.float32, device=dev)
+    with torch.no_grad():
+        act = synth.activate({k: v.detach() for k, v in mapper.params.items()})
+        args = [act[k].contiguous() for k in ("means3D", "colors", "opacities", "scales", "rotations")]
+        for c2w, kf in zip(c2w_list, kf_ids):
+            w2c = torch.linalg.inv(c2w.to(dev))
+            surfel.view_importance(*args, view_settings(w2c, intr), out=cur, accumulate=False,
+                                   rgb_max=rgb_max)
+            if float(rgb_max) < 0.1:      # the reference's own host-side test (loop_model.py:181)
+                continue
+            _lib.check(L.vings_splat_top3_update(n, _lib.ptr(cur), int(kf), _lib.ptr(scores3),
+                                                 _lib.ptr(ids3), _lib.stream_ptr(dev)),
+                       "vings_splat_top3_update")
+    return scores3, ids3
+
+
+def _quat_wxyz_from_matrix(R):
+    """Unit quaternions (w,x,y,z) of rotation matrices [K,3,3] (float64 on the host)."""
+    R = R.double().cpu()
+    K = R.shape[0]
+    q = torch.zeros(K, 4, dtype=torch.float64)
+    for k in range(K):
+        m = R[k]
+        t = m[0, 0] + m[1, 1] + m[2, 2]
+        if t > 0:
+            s = torch.sqrt(t + 1.0) * 2
+            q[k] = torch.stack([0.25 * s, (m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s,
+                                (m[1, 0] - m[0, 1]) / s])
+        elif m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]:
+            s = torch.sqrt(1.0 + m[0, 0] - m[1, 1] - m[2, 2]) * 2
+            q[k] = torch.stack([(m[2, 1] - m[1, 2]) / s, 0.25 * s, (m[0, 1] + m[1, 0]) / s,
+                                (m[0, 2] + m[2, 0]) / s])
+        elif m[1, 1] > m[2, 2]:
+            s = torch.sqrt(1.0 + m[1, 1] - m[0, 0] - m[2, 2]) * 2
+            q[k] = torch.stack([(m[0, 2] - m[2, 0]) / s, (m[0, 1] + m[1, 0]) / s, 0.25 * s,
+                                (m[1, 2] + m[2, 1]) / s])
+        else:
+            s = torch.sqrt(1.0 + m[2, 2] - m[0, 0] - m[1, 1]) * 2
+            q[k] = torch.stack([(m[1, 0] - m[0, 1]) / s, (m[0, 2] + m[2, 0]) / s,
+                                (m[1, 2] + m[2, 1]) / s, 0.25 * s])
+    return q / q.norm(dim=1, keepdim=True)
+
+
+def rectify_gaussians(mapper, raw_c2ws, new_c2ws, new_scales, start_kf, end_kf, scores3, ids3,
+                      delete_below=0.1):
+    """Move the splats owned (best keyframe) by keyframes start_kf..end_kf with their
+    keyframe's pose correction and per-keyframe scale, then delete the splats whose best score
+    is below `delete_below` (loop_rectify.py:300-382).  raw_c2ws / new_c2ws: [K,4,4];
+    new_scales: one scale per keyframe of the loop (end_kf - start_kf + 1 values).
+    Rotations are handled as (w,x,y,z) quaternions (the reference's round trip through
+    (x,y,z,w) libraries is not reproduced)."""
+    L = _lib.lib()
+    dev, n = mapper.device, mapper.n
+    raw = raw_c2ws.double().cpu()
+    new = new_c2ws.double().cpu()
+    K = raw.shape[0]
+    old_w2c = torch.linalg.inv(raw)
+    delta = new @ old_w2c
+    dq = _quat_wxyz_from_matrix(delta[:, :3, :3])
+    scale = torch.ones(K, dtype=torch.float64)
+    scale[start_kf:end_kf + 1] = new_scales.double().cpu().reshape(-1)
+    f = lambda t: t.float().contiguous().to(dev)
+    t_old, t_new = f(old_w2c[:, :3, :].reshape(K, 12)), f(new[:, :3, :].reshape(K, 12))
+    t_dq, t_scale = f(dq), f(scale)
+    ids3 = ids3.contiguous()
+    with torch.no_grad():
+        _lib.check(L.vings_splat_reanchor(
+            n, _lib.ptr(mapper.params["_xyz"].data), _lib.ptr(mapper.params["_rotation"].data),
+            _lib.ptr(ids3), 3, int(start_kf), int(end_kf), K, _lib.ptr(t_old), _lib.ptr(t_new),
+            _lib.ptr(t_dq), _lib.ptr(t_scale), _lib.stream_ptr(dev)), "vings_splat_reanchor")
+    delete_mask = scores3[:, 0] < delete_below
+    prune(mapper, delete_mask)
+    return delete_mask
+
+
 def stablemask_control(mapper):
     """End-of-window stable-mask update and reset of the window scores
     (gaussian_model.py:190-200)."""

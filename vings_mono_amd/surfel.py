@@ -61,10 +61,11 @@ def rasterize_forward(means3D, colors, opacities, scales, rotations, settings, k
 
 
 def view_importance(means3D, colors, opacities, scales, rotations, settings, out=None,
-                    accumulate=False):
+                    accumulate=False, rgb_max=None):
     """Per-splat blend weight mass sum(alpha*T) of one view without rendering an image or
     running a backward pass (= scores.grad[:,0] of the reference's render + backward,
-    gaussian_model.py:233-241).  Returns (importance[N], radii[N])."""
+    gaussian_model.py:233-241).  Returns (importance[N], radii[N]).  `rgb_max`: optional
+    1-element float tensor that receives the largest colour value the view would render."""
     L = _lib.lib()
     st, aux = _forward(means3D, colors, opacities, scales, rotations, settings, False, False)
     N = st.N
@@ -74,7 +75,7 @@ def view_importance(means3D, colors, opacities, scales, rotations, settings, out
     mask = aux[3]
     check(L.vings_surfel_blend_importance(N, st.H, st.W, ptr(st.ranges), ptr(st.vals), ptr(st.geom),
                                           ptr(mask), ptr(out), 1 if accumulate else 0,
-                                          stream_ptr(means3D.device)),
+                                          ptr(aux[2]), ptr(rgb_max), stream_ptr(means3D.device)),
           "vings_surfel_blend_importance")
     return out, st.radii
 
