@@ -1,0 +1,70 @@
+"""On-disk formats (PLY, .pt checkpoint) in the reference's layout
+(/root/reference/scripts/gaussian/vis_utils.py:186-310,
+/root/reference/scripts/gaussian/gaussian_base.py:492-525).  Parity unpinned: the reference
+tree holds no sample file; checked are the header text, field order, value encoding and the
+round trip.  Runs on CPU."""
+import numpy as np
+import pytest
+import torch
+
+from vings_mono_amd import harness, io_formats, synth
+
+
+@pytest.mark.parametrize("mode,nscale", [("2dgs", 2), ("3dgs", 3), ("sky", 3)])
+def test_ply_layout_and_round_trip(tmp_path, mode, nscale):
+    raw = synth.make_splats(257, 64, 48, seed=3)
+    path = tmp_path / f"map_{mode}.ply"
+    io_formats.save_ply(raw, str(path), mode)
+    blob = path.read_bytes()
+    head, body = blob.split(b"end_header\n", 1)
+    lines = head.decode("ascii").splitlines()
+    assert lines[:3] == ["ply", "format binary_little_endian 1.0", "element vertex 257"]
+    props = [l.split()[2] for l in lines[3:]]
+    assert all(l.startswith("property float ") for l in lines[3:])
+    want = ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"] + \
+           [f"f_rest_{i}" for i in range(45)] + ["opacity"] + [f"scale_{i}" for i in range(nscale)] + \
+           [f"rot_{i}" for i in range(4)]
+    assert props == want
+    table = np.frombuffer(body, "<f4").reshape(257, len(want))
+    np.testing.assert_array_equal(table[:, 0:3], raw["_xyz"].numpy())
+    assert not table[:, 3:6].any() and not table[:, 9:54].any()        # normals, higher SH
+    np.testing.assert_allclose(table[:, 6:9], (raw["_rgb"].numpy() - 0.5) / io_formats.C0, rtol=1e-6)
+    np.testing.assert_array_equal(table[:, 54], raw["_opacity"].numpy()[:, 0])
+    np.testing.assert_array_equal(table[:, 55:57], raw["_scaling"].numpy())
+    if nscale == 3:
+        assert np.all(table[:, 57] == -10.0)
+    np.testing.assert_array_equal(table[:, -4:], raw["_rotation"].numpy())
+    back = io_formats.load_ply(str(path))
+    assert back["_scaling"].shape == (257, 2) and back["_opacity"].shape == (257, 1)
+    for k in ("_xyz", "_opacity", "_scaling", "_rotation"):
+        np.testing.assert_array_equal(back[k].astype(np.float32), raw[k].numpy())
+    np.testing.assert_allclose(back["_rgb"], raw["_rgb"].numpy(), atol=1e-6)
+
+
+def test_ply_reader_rejects_other_layouts(tmp_path):
+    p = tmp_path / "ascii.ply"
+    p.write_text("ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nend_header\n0\n")
+    with pytest.raises(ValueError):
+        io_formats.load_ply(str(p))
+    p.write_text("plx\n")
+    with pytest.raises(ValueError):
+        io_formats.load_ply(str(p))
+
+
+def test_checkpoint_uses_reference_names_and_round_trips(tmp_path):
+    raw = synth.make_splats(100, 64, 48, seed=5)
+    m = harness.SurfelMapper(raw, "cpu")
+    m.global_scores[:, 0] = torch.arange(100.0)
+    m.stable_mask[::3] = True
+    m.globalkf_id[:] = 7
+    path = str(tmp_path / "ckpt.pt")
+    io_formats.save_pt_ckpt(m, path)
+    d = torch.load(path, weights_only=True)
+    assert sorted(d) == sorted(["_xyz", "_rgb", "_scaling", "_rotation", "_opacity", "_global_scores",
+                                "_local_scores", "_stable_mask", "_globalkf_id", "_globalkf_max_scores"])
+    assert d["_stable_mask"].dtype == torch.bool and d["_globalkf_id"].dtype == torch.int64
+    m2 = io_formats.load_pt_ckpt(path, "cpu")
+    for k in m.NAMES:
+        assert torch.equal(m2.params[k].detach(), m.params[k].detach())
+    assert torch.equal(m2.global_scores, m.global_scores)
+    assert torch.equal(m2.stable_mask, m.stable_mask) and torch.equal(m2.globalkf_id, m.globalkf_id)
