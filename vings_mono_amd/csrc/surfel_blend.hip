@@ -34,6 +34,9 @@ constexpr float kAlphaMax = 0.99f;
 constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kTMin = 0.0001f;
 constexpr int kBatch = 256;
+// backward batch: 248 records keep the kernel at 40.8 KB of LDS, i.e. four workgroups per
+// CU (160 KB) instead of three with 256
+constexpr int kBatchBwd = 248;
 constexpr int kRec4 = VINGS_GEOM_STRIDE / 4;  // float4 per record
 constexpr int kGrad = VINGS_GRAD_STRIDE;      // gradient components per splat
 
@@ -440,9 +443,9 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
     const uint8_t* __restrict__ pixel_mask, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_dallmap, float* __restrict__ dgeom) {
-    __shared__ float4 rec[kBatch * (kRec4 - 1)];
-    __shared__ float acc[kBatch * kGrad];
-    __shared__ uint32_t ids[kBatch];
+    __shared__ float4 rec[kBatchBwd * (kRec4 - 1)];
+    __shared__ float acc[kBatchBwd * kGrad];
+    __shared__ uint32_t ids[kBatchBwd];
     __shared__ unsigned long long hit[16];
     __shared__ uint32_t wmax[4];
     const int tile = blockIdx.x;
@@ -496,10 +499,10 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
     // S = sum_c value_c * dL/dchannel_c: one scalar pair replaces 14 per-channel pairs.
     float T = T_final, last_alpha = 0.f, B = 0.f, S_last = 0.f;
 
-    const int nbatch = (int)((maxlast + kBatch - 1) / kBatch);
+    const int nbatch = (int)((maxlast + kBatchBwd - 1) / kBatchBwd);
     for (int b = nbatch - 1; b >= 0; --b) {
-        const uint32_t bstart = (uint32_t)b * kBatch;
-        const int cnt = (int)min((uint32_t)kBatch, maxlast - bstart);
+        const uint32_t bstart = (uint32_t)b * kBatchBwd;
+        const int cnt = (int)min((uint32_t)kBatchBwd, maxlast - bstart);
         __syncthreads();  // previous batch fully flushed
         stage_batch(rec, hit, geom, vals, r0 + bstart + threadIdx.x, r0 + bstart + cnt, ids,
                     (float)(tx * 16), (float)(ty * 16));
