@@ -34,9 +34,10 @@ constexpr float kAlphaMax = 0.99f;
 constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kTMin = 0.0001f;
 constexpr int kBatch = 256;
-// backward batch: 248 records keep the kernel at 40.8 KB of LDS, i.e. four workgroups per
-// CU (160 KB) instead of three with 256
-constexpr int kBatchBwd = 248;
+// backward batch: 192 records keep the kernel at 31.6 KB of LDS, i.e. five workgroups per
+// CU (160 KB) instead of three with 256; its launch bound asks for 5 waves per SIMD (96
+// VGPRs: the staging code spills a little, the blend loop does not)
+constexpr int kBatchBwd = 192;
 constexpr int kRec4 = VINGS_GEOM_STRIDE / 4;  // float4 per record
 constexpr int kGrad = VINGS_GRAD_STRIDE;      // gradient components per splat
 
@@ -437,7 +438,7 @@ __device__ __forceinline__ void row_mirror_add5(float& a, float& b, float& c, fl
         : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
 }
 
-__global__ __launch_bounds__(256) void blend_bwd_kernel(
+__global__ __launch_bounds__(256, 5) void blend_bwd_kernel(
     int H, int W, int gx, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ vals,
     const float* __restrict__ geom, const float* __restrict__ bg,
     const uint8_t* __restrict__ pixel_mask, const float* __restrict__ final_T,
