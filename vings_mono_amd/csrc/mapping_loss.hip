@@ -94,11 +94,12 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, Gauss gw,
     const int tx0 = blockIdx.x * kST, ty0 = blockIdx.y * kST;
     const int c = threadIdx.x & 31, rq = threadIdx.x >> 5;  // output column, first output row
     double ssim_acc = 0.0, l1_acc = 0.0;
-    // validity of this lane's four output pixels (rows rq, rq+8, rq+16, rq+24)
+    // validity of this lane's four output pixels: rows 4 rq .. 4 rq + 3 of column c, so the
+    // vertical filter reads 14 rows of the horizontal result for 4 outputs instead of 44
     bool vld[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int gy = ty0 + rq + 8 * i, gx = tx0 + c;
+        const int gy = ty0 + 4 * rq + i, gx = tx0 + c;
         vld[i] = false;
         if (gy < H && gx < W) {
             const size_t p = (size_t)gy * W + gx;
@@ -119,32 +120,58 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, Gauss gw,
             sx[r][cc] = xv; sy[r][cc] = yv;
         }
         __syncthreads();
-        for (int idx = threadIdx.x; idx < kSIn * kST; idx += 256) {
-            const int r = idx >> 5, cc = idx & 31;
-            float m1 = 0, m2 = 0, e11 = 0, e22 = 0, e12 = 0;
+        // horizontal pass: a lane produces 4 neighbouring columns of one row from 14 reads
+        for (int idx = threadIdx.x; idx < kSIn * (kST / 4); idx += 256) {
+            const int r = idx >> 3, c0 = (idx & 7) * 4;
+            float hm[5][4];
 #pragma unroll
-            for (int k = 0; k < kWin; ++k) {
-                const float xv = sx[r][cc + k], yv = sy[r][cc + k], g = gw.g[k];
-                const float gx_ = g * xv, gy_ = g * yv;
-                m1 += gx_; m2 += gy_;
-                e11 += gx_ * xv; e22 += gy_ * yv; e12 += gx_ * yv;
+            for (int m = 0; m < 5; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hm[m][i] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < kWin + 3; ++kk) {
+                const float xv = sx[r][c0 + kk], yv = sy[r][c0 + kk];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (kk - i >= 0 && kk - i < kWin) {
+                        const float g = gw.g[kk - i];
+                        const float gx_ = g * xv, gy_ = g * yv;
+                        hm[0][i] += gx_; hm[1][i] += gy_;
+                        hm[2][i] += gx_ * xv; hm[3][i] += gy_ * yv; hm[4][i] += gx_ * yv;
+                    }
+                }
             }
-            hz[0][r][cc] = m1; hz[1][r][cc] = m2; hz[2][r][cc] = e11; hz[3][r][cc] = e22;
-            hz[4][r][cc] = e12;
+#pragma unroll
+            for (int m = 0; m < 5; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hz[m][r][c0 + i] = hm[m][i];
         }
         __syncthreads();
+        float vm[5][4];
+#pragma unroll
+        for (int m = 0; m < 5; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vm[m][i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < kWin + 3; ++kk) {     // sliding window over 14 rows
+            float hv[5];
+#pragma unroll
+            for (int m = 0; m < 5; ++m) hv[m] = hz[m][4 * rq + kk][c];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (kk - i >= 0 && kk - i < kWin) {
+                    const float g = gw.g[kk - i];
+#pragma unroll
+                    for (int m = 0; m < 5; ++m) vm[m][i] += g * hv[m];
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = rq + 8 * i;
+            const int r = 4 * rq + i;
             const int gy = ty0 + r, gx = tx0 + c;
-            float mu1 = 0, mu2 = 0, e11 = 0, e22 = 0, e12 = 0;
-#pragma unroll
-            for (int k = 0; k < kWin; ++k) {
-                const float g = gw.g[k];
-                mu1 += g * hz[0][r + k][c]; mu2 += g * hz[1][r + k][c];
-                e11 += g * hz[2][r + k][c]; e22 += g * hz[3][r + k][c];
-                e12 += g * hz[4][r + k][c];
-            }
+            const float mu1 = vm[0][i], mu2 = vm[1][i], e11 = vm[2][i], e22 = vm[3][i],
+                        e12 = vm[4][i];
             if (gy < H && gx < W) {
                 const size_t p = (size_t)gy * W + gx;
                 const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
@@ -196,7 +223,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, Gauss gw, f
     bool vld[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int gy = ty0 + rq + 8 * i, gx = tx0 + c;
+        const int gy = ty0 + 4 * rq + i, gx = tx0 + c;   // rows 4 rq .. 4 rq + 3 of column c
         vld[i] = false;
         if (gy < H && gx < W) {
             const size_t p = (size_t)gy * W + gx;
@@ -214,27 +241,53 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, Gauss gw, f
                 sm[m][r][cc] = in ? maps[(size_t)(3 * ch + m) * HW + p] : 0.f;
         }
         __syncthreads();
-        for (int idx = threadIdx.x; idx < kSIn * kST; idx += 256) {
-            const int r = idx >> 5, cc = idx & 31;
-            float f0 = 0, f1 = 0, f2 = 0;
+        // both passes as sliding windows: 14 reads feed 4 neighbouring outputs
+        for (int idx = threadIdx.x; idx < kSIn * (kST / 4); idx += 256) {
+            const int r = idx >> 3, c0 = (idx & 7) * 4;
+            float hm[3][4];
 #pragma unroll
-            for (int k = 0; k < kWin; ++k) {
-                const float g = gw.g[k];
-                f0 += g * sm[0][r][cc + k]; f1 += g * sm[1][r][cc + k]; f2 += g * sm[2][r][cc + k];
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hm[m][i] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < kWin + 3; ++kk) {
+                const float v0 = sm[0][r][c0 + kk], v1 = sm[1][r][c0 + kk], v2 = sm[2][r][c0 + kk];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (kk - i >= 0 && kk - i < kWin) {
+                        const float g = gw.g[kk - i];
+                        hm[0][i] += g * v0; hm[1][i] += g * v1; hm[2][i] += g * v2;
+                    }
+                }
             }
-            hz[0][r][cc] = f0; hz[1][r][cc] = f1; hz[2][r][cc] = f2;
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hz[m][r][c0 + i] = hm[m][i];
         }
         __syncthreads();
+        float vm[3][4];
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vm[m][i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < kWin + 3; ++kk) {
+            const float v0 = hz[0][4 * rq + kk][c], v1 = hz[1][4 * rq + kk][c],
+                        v2 = hz[2][4 * rq + kk][c];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (kk - i >= 0 && kk - i < kWin) {
+                    const float g = gw.g[kk - i];
+                    vm[0][i] += g * v0; vm[1][i] += g * v1; vm[2][i] += g * v2;
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = rq + 8 * i;
+            const int r = 4 * rq + i;
             const int gy = ty0 + r, gx = tx0 + c;
-            float f0 = 0, f1 = 0, f2 = 0;
-#pragma unroll
-            for (int k = 0; k < kWin; ++k) {
-                const float g = gw.g[k];
-                f0 += g * hz[0][r + k][c]; f1 += g * hz[1][r + k][c]; f2 += g * hz[2][r + k][c];
-            }
+            const float f0 = vm[0][i], f1 = vm[1][i], f2 = vm[2][i];
             if (gy < H && gx < W) {
                 const size_t p = (size_t)gy * W + gx;
                 const float x = rgb[ch * HW + p], y = gt_rgb[ch * HW + p];
