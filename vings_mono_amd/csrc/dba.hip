@@ -138,9 +138,72 @@ __device__ __forceinline__ Se3d relative_pose(const float* __restrict__ poses, i
     return G;
 }
 
+// float64 wave sum without LDS traffic: DPP inside the 16-lane rows (each half of the double
+// moved separately), v_permlane16_swap / v_permlane32_swap across rows.  The shuffle form
+// (two ds_bpermute per step and value) kept the LDS pipe busier than the arithmetic did.
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+// k32: lanes 0-31 receive a[l] + a[l+32], lanes 32-63 receive b[l-32] + b[l];
+// otherwise the same for even / odd 16-lane rows.
+template <bool k32>
+__device__ __forceinline__ double swap_add_d2(double a, double b) {
+    const unsigned long long ba = __builtin_bit_cast(unsigned long long, a);
+    const unsigned long long bb = __builtin_bit_cast(unsigned long long, b);
+    const unsigned alo = (unsigned)ba, ahi = (unsigned)(ba >> 32);
+    const unsigned blo = (unsigned)bb, bhi = (unsigned)(bb >> 32);
+    unsigned l0, l1, h0, h1;
+    if (k32) {
+        const auto rl = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        const auto rh = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        l0 = rl[0]; l1 = rl[1]; h0 = rh[0]; h1 = rh[1];
+    } else {
+        const auto rl = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        const auto rh = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        l0 = rl[0]; l1 = rl[1]; h0 = rh[0]; h1 = rh[1];
+    }
+    asm volatile("" : "+v"(l0), "+v"(l1), "+v"(h0), "+v"(h1));  // keep the two results apart
+    const double x = __builtin_bit_cast(double, ((unsigned long long)h0 << 32) | l0);
+    const double y = __builtin_bit_cast(double, ((unsigned long long)h1 << 32) | l1);
+    return x + y;
+}
+__device__ __forceinline__ double row_sum_d(double v) {
+    v += dpp_d<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_d<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_d<0x141>(v);   // row_half_mirror
+    v += dpp_d<0x140>(v);   // row_mirror
+    return v;
+}
+template <bool k32>
+__device__ __forceinline__ double swap_add_d(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+    unsigned l0, l1, h0, h1;
+    if (k32) {
+        const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        l0 = rl[0]; l1 = rl[1]; h0 = rh[0]; h1 = rh[1];
+    } else {
+        const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        l0 = rl[0]; l1 = rl[1]; h0 = rh[0]; h1 = rh[1];
+    }
+    asm volatile("" : "+v"(l0), "+v"(l1), "+v"(h0), "+v"(h1));  // keep the two results apart
+    const double x = __builtin_bit_cast(double, ((unsigned long long)h0 << 32) | l0);
+    const double y = __builtin_bit_cast(double, ((unsigned long long)h1 << 32) | l1);
+    return x + y;
+}
 __device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    v += dpp_d<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_d<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_d<0x141>(v);   // row_half_mirror
+    v += dpp_d<0x140>(v);   // row_mirror
+    v = swap_add_d<false>(v);
+    v = swap_add_d<true>(v);
     return v;
 }
 
@@ -306,10 +369,23 @@ __global__ __launch_bounds__(256) void dba_linearize_kernel(
             hacc[78 + a] = wt[0] * Ji[0][a] * r[0] + wt[1] * Ji[1][a] * r[1];
             hacc[84 + a] = wt[0] * Jj[0][a] * r[0] + wt[1] * Jj[1][a] * r[1];
         }
+        // Transposing wave reduction of the 90 sums (padded to 92): a permlane32 swap + add
+        // sums two values over lanes l / l+32 and leaves one per half, a permlane16 swap + add
+        // does the same for rows; 23 registers then hold four values each (row r of register k
+        // = value 4k + {0,2,1,3}[r]) and a DPP row sum finishes them.
+        {
+            double v46[46];
 #pragma unroll
-        for (int q = 0; q < kNH; ++q) {
-            const double s = wave_sum_f64(hacc[q]);
-            if (lane == 0) red[wv][q] = s;
+            for (int q = 0; q < 45; ++q) v46[q] = swap_add_d2<true>(hacc[2 * q], hacc[2 * q + 1]);
+            v46[45] = 0.0;
+            const int row = lane >> 4;
+            const int comp0 = ((row & 1) << 1) | (row >> 1);
+#pragma unroll
+            for (int q = 0; q < 23; ++q) {
+                const double u = row_sum_d(swap_add_d2<false>(v46[2 * q], v46[2 * q + 1]));
+                const int dst = 4 * q + comp0;
+                if ((lane & 15) == 0 && dst < kNH) red[wv][dst] = u;
+            }
         }
         __syncthreads();
         const int n6 = 6 * P;
