@@ -220,6 +220,14 @@ int vings_splat_compact_apply(int N, const int32_t* dst_index, int n_arrays,
                               const int* row_bytes_host, void* stream);
 
 /* ------------------------------------------------------------------------
+ * mean_dist2[i] = mean of the squared distances from point i to its three nearest other
+ * points; xyz[N,3].  Serves distCUDA2 (gaussian_utils.py:12-16; callers gaussian_model.py:72,
+ * 139: initial scale of new splats), which the reference runs as a k-d tree on the host.
+ * N >= 4.
+ */
+int vings_knn3_mean_dist2(int N, const float* xyz, float* mean_dist2, void* stream);
+
+/* ------------------------------------------------------------------------
  * Loop closure, per-splat stages.
  * top3_update: folds the importance of one more keyframe view into every splat's record of
  *   its three best keyframes, scores3[N,3] (descending) and kfids3[N,3] (int32), with the

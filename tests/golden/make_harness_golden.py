@@ -8,6 +8,7 @@ absent native extensions):
   gaussian.loss_utils.get_loss (+ autograd gradients)   loss_utils.py:110-153
   gaussian.normal_utils.depth_propagate_normal + TFer   normal_utils.py:6-21, tf.py:133-142
   gaussian.gaussian_utils.weighting_grad                gaussian_utils.py:56-62
+  gaussian.gaussian_utils.distCUDA2                     gaussian_utils.py:12-16
 
 Usage:  python tests/golden/make_harness_golden.py
 """
@@ -90,6 +91,11 @@ def main():
     out["wg_cur"], out["wg_glob"] = cur.numpy(), glob.numpy()
     for k in shapes:
         out["wg_out_" + k] = getattr(m, k).grad.numpy()
+    # ---- mean squared distance to the 3 nearest neighbours (scale of new splats) ---------
+    pts = torch.randn(3000, 3, generator=g) * torch.tensor([4.0, 2.0, 8.0])
+    pts[10] = pts[11]                        # a duplicated point: its zero distance counts
+    out["knn_points"] = pts.numpy()
+    out["knn_dist2"] = ref_gutils.distCUDA2(pts).numpy()
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 

@@ -192,3 +192,71 @@ def test_storage_control_prunes_by_forward_importance():
     assert m.n == n0 - int(mask.sum())
     maintenance.stablemask_control(m)
     assert float(m.local_scores.abs().max()) == 0.0
+
+
+def test_knn3_mean_dist2_matches_reference_golden():
+    """Against outputs of the reference's distCUDA2 (k-d tree, float32 sums) on 3000 points;
+    float tolerance 1e-5 relative (the summation order of three squares differs)."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                "harness_golden.npz"))
+    pts = torch.from_numpy(gold["knn_points"]).to(DEV)
+    got = maintenance.mean_dist2_to_3nn(pts).cpu().numpy()
+    np.testing.assert_allclose(got, gold["knn_dist2"], rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.parametrize("n", [4, 257, 5000])
+def test_knn3_mean_dist2_brute_force(n):
+    g = torch.Generator().manual_seed(n)
+    pts = torch.rand(n, 3, generator=g)
+    pts[n // 2] = pts[0]                                  # a duplicate: distance 0 counts
+    d = torch.cdist(pts.double(), pts.double()) ** 2
+    d.fill_diagonal_(float("inf"))
+    want = d.topk(3, dim=1, largest=False).values.mean(1).float()
+    got = maintenance.mean_dist2_to_3nn(pts.to(DEV)).cpu()
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-9)
+
+
+def test_knn3_rejects_too_few_points():
+    from vings_mono_amd._lib import VingsError
+    with pytest.raises(VingsError):
+        maintenance.mean_dist2_to_3nn(torch.rand(3, 3, device=DEV))
+    assert maintenance.mean_dist2_to_3nn(torch.zeros(0, 3, device=DEV)).shape == (0,)
+
+
+def test_add_splats_extends_parameters_state_and_records():
+    dev = torch.device(DEV)
+    W, H = 160, 96
+    raw = synth.make_splats(3000, W, H, n_views=2, seed=21)
+    extra = synth.make_splats(700, W, H, n_views=2, seed=22)
+    intr = synth.intrinsic_for(W, H)
+    w2c = torch.linalg.inv(synth.window_poses(2)[1]).to(dev)
+    gtp = {k: v.to(dev) for k, v in synth.perturb_splats(raw).items()}
+    with torch.no_grad():
+        pr = harness.render(gtp, w2c, intr)
+        gt = {"rgb": pr["rgb"].clone(), "depth": pr["depth"].clone(),
+              "depth_cov": torch.ones_like(pr["depth"])}
+    m = harness.SurfelMapper(raw, dev)
+    cam = harness.view_settings(w2c, intr)
+    m.fused_view(cam, intr, gt, w2c[:3, :3].cpu(), 0)
+    before = {k: m.params[k].detach().clone() for k in m.NAMES}
+    mom = {k: m.optimizer.state[m.params[k]]["exp_avg"].clone() for k in m.NAMES}
+    new = maintenance.new_splat_params(extra["_xyz"].to(dev), extra["_rgb"].to(dev),
+                                       extra["_rotation"].to(dev))
+    # the reference's initial values: isotropic log-scale from the 3-NN distance, opacity 0.8
+    d2 = maintenance.mean_dist2_to_3nn(extra["_xyz"].to(dev)).clamp_min(1e-7)
+    assert torch.equal(new["_scaling"], torch.log(torch.sqrt(d2))[:, None].repeat(1, 2))
+    assert torch.allclose(torch.sigmoid(new["_opacity"]), torch.full((700, 1), 0.8, device=dev))
+    total = maintenance.add_splats(m, new)
+    assert total == 3700 == m.n
+    for k in m.NAMES:
+        assert torch.equal(m.params[k].detach()[:3000], before[k])
+        assert torch.equal(m.params[k].detach()[3000:], new[k].reshape(700, -1))
+        st = m.optimizer.state[m.params[k]]
+        assert torch.equal(st["exp_avg"][:3000], mom[k])
+        assert float(st["exp_avg"][3000:].abs().max()) == 0.0
+        assert float(st["exp_avg_sq"][3000:].abs().max()) == 0.0
+    assert m.global_scores.shape == (3700, 2) and m.stable_mask.shape == (3700,)
+    assert float(m.global_scores[3000:].abs().max()) == 0.0
+    loss = m.fused_view(cam, intr, gt, w2c[:3, :3].cpu(), 1)    # the grown map still trains
+    assert torch.isfinite(loss).all()

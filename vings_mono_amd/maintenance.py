@@ -111,6 +111,60 @@ def storage_control(mapper, w2c_list, intr, low=0.05, high=0.8):
     return mask
 
 
+def mean_dist2_to_3nn(points):
+    """distCUDA2 (gaussian_utils.py:12-16) on the device: mean squared distance of every
+    point [N,3] to its three nearest other points."""
+    L = _lib.lib()
+    _lib.require_gpu_tensor(points, "points", torch.float32)
+    pts = points.contiguous()
+    out = torch.empty(pts.shape[0], dtype=torch.float32, device=pts.device)
+    _lib.check(L.vings_knn3_mean_dist2(pts.shape[0], _lib.ptr(pts), _lib.ptr(out),
+                                       _lib.stream_ptr(pts.device)), "vings_knn3_mean_dist2")
+    return out
+
+
+def new_splat_params(points, colors, rotations, opacity=0.8):
+    """Stored (pre-activation) parameters of splats created from a point cloud, as
+    add_new_frame / init_first_frame set them (gaussian_model.py:72-80,139-149): isotropic
+    log-scale from the 3-nearest-neighbour distance, opacity logit of `opacity`."""
+    dist2 = mean_dist2_to_3nn(points).clamp_min(0.0000001)
+    log_scales = torch.log(torch.sqrt(dist2))[:, None].repeat(1, 2)
+    logit = float(torch.log(torch.tensor(opacity / (1.0 - opacity))))
+    n = points.shape[0]
+    return {"_xyz": points.float().contiguous(), "_rgb": colors.float().contiguous(),
+            "_scaling": log_scales.contiguous(), "_rotation": rotations.float().contiguous(),
+            "_opacity": torch.full((n, 1), logit, dtype=torch.float32, device=points.device)}
+
+
+def add_splats(mapper, new_params):
+    """Append splats to a harness.SurfelMapper: parameters concatenated, Adam moments and
+    score records extended with zeros (cat_tensors_to_optimizer gaussian_base.py:74-92,
+    update_records(mode="densify") gaussian_model.py:171-176)."""
+    k = new_params["_xyz"].shape[0]
+    dev = mapper.device
+    for group in mapper.optimizer.param_groups:
+        name = group["name"]
+        old = group["params"][0]
+        ext = new_params[name].to(dev).float().reshape((k,) + tuple(old.shape[1:]))
+        state = mapper.optimizer.state.pop(old, None)
+        p = torch.nn.Parameter(torch.cat((old.detach(), ext), dim=0).requires_grad_(True))
+        group["params"][0] = p
+        mapper.params[name] = p
+        if state:
+            state["exp_avg"] = torch.cat((state["exp_avg"], torch.zeros_like(ext)), dim=0)
+            state["exp_avg_sq"] = torch.cat((state["exp_avg_sq"], torch.zeros_like(ext)), dim=0)
+            mapper.optimizer.state[p] = state
+    z = lambda *s, dt: torch.zeros(*s, dtype=dt, device=dev)
+    mapper.global_scores = torch.cat((mapper.global_scores, z(k, 2, dt=torch.float32)))
+    mapper.local_scores = torch.cat((mapper.local_scores, z(k, 2, dt=torch.float32)))
+    mapper.stable_mask = torch.cat((mapper.stable_mask, z(k, dt=torch.bool)))
+    mapper.globalkf_id = torch.cat((mapper.globalkf_id, z(k, dt=torch.int64)))
+    mapper.globalkf_max_scores = torch.cat((mapper.globalkf_max_scores, z(k, dt=torch.float32)))
+    mapper.n += k
+    mapper._fb = None
+    return mapper.n
+
+
 def calc_score(mapper, c2w_list, kf_ids, intr):
     """Top-3 keyframes of every splat by blend-weight mass (loop_model.py:169-214): returns
     (scores [N,3] descending, kf ids [N,3] int32).  One forward-only importance pass per
