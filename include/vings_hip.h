@@ -227,6 +227,15 @@ int vings_splat_compact_apply(int N, const int32_t* dst_index, int n_arrays,
  */
 int vings_knn3_mean_dist2(int N, const float* xyz, float* mean_dist2, void* stream);
 
+/* World position and colour of n chosen pixels of a new keyframe (get_pointcloud,
+ * gaussian_utils.py:39-46 with tf.py:46-68): pixel_ids[n] are row-major indices into
+ * depth[H,W] / rgb[3,H,W]; pixel (row u, column v) of depth z maps to the camera point
+ * ((v-cv)/fv*z, (u-cu)/fu*z, z) and through c2w_host (16 host floats, row major).
+ * Writes xyz[n,3], colors[n,3]. */
+int vings_keyframe_backproject(int n, int H, int W, const int64_t* pixel_ids, const float* depth,
+                               const float* rgb, const float* c2w_host, float fu, float fv,
+                               float cu, float cv, float* xyz, float* colors, void* stream);
+
 /* ------------------------------------------------------------------------
  * Loop closure, per-splat stages.
  * top3_update: folds the importance of one more keyframe view into every splat's record of
@@ -239,7 +248,15 @@ int vings_knn3_mean_dist2(int N, const float* xyz, float* mean_dist2, void* stre
  *   major), delta_quat [K,4] (w,x,y,z; the rotation of new_c2w * old_w2c), scale [K].
  *   Quaternions are (w,x,y,z) throughout, as the rasteriser reads them; the reference
  *   round-trips this step through (x,y,z,w) libraries -- flagged, not reproduced.
+ * depth_refresh: the tracker-side refresh after a loop closure (rectify_tracker,
+ *   loop/loop_rectify.py:420-426) from the two rasteriser channels depth_sum[H,W] and
+ *   alpha[H,W]: d = depth_sum/alpha with NaN and +inf -> 0 (gaussian_base.py:205-209);
+ *   dense_map[H,W] takes d wherever d > 0 (in place, other pixels keep their value);
+ *   coarse_map[H/8,W/8] = mean of the four centre pixels (rows/columns 3,4) of every 8x8
+ *   block of the updated dense_map.  H and W must be multiples of 8.
  */
+int vings_depth_refresh(int H, int W, const float* depth_sum, const float* alpha,
+                        float* dense_map, float* coarse_map, void* stream);
 int vings_splat_top3_update(int N, const float* cur_importance, int kf_id, float* scores3,
                             int32_t* kfids3, void* stream);
 int vings_splat_reanchor(int N, float* xyz, float* rotation, const int32_t* owner_kf,

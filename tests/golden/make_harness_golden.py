@@ -96,6 +96,26 @@ def main():
     pts[10] = pts[11]                        # a duplicated point: its zero distance counts
     out["knn_points"] = pts.numpy()
     out["knn_dist2"] = ref_gutils.distCUDA2(pts).numpy()
+    # ---- point cloud of a new keyframe (get_pointcloud, gaussian_utils.py:19-54) ----------
+    Hp, Wp = 36, 52
+    pintr = {"fu": 41.0, "fv": 43.5, "cu": 17.2, "cv": 26.1, "H": Hp, "W": Wp}
+    ptfer = TFer({"intrinsic": pintr, "device": {"mapper": "cpu"}, "adc_args": {"accum_thresh": 0.6}})
+    pdepth = torch.rand(1, Hp, Wp, generator=g) * 6 + 0.5
+    pdepth[:, :, :5] = 0.0
+    pdepth[:, 30:, 40:] = 0.0
+    prgb = torch.rand(3, Hp, Wp, generator=g)
+    paccum = torch.rand(1, Hp, Wp, generator=g)
+    ang = 0.3
+    pc2w = torch.tensor([[math.cos(ang), 0.0, math.sin(ang), 1.5], [0.0, 1.0, 0.0, -0.4],
+                         [-math.sin(ang), 0.0, math.cos(ang), 2.0], [0.0, 0.0, 0.0, 1.0]])
+    torch.manual_seed(77)
+    xyz, col, q = ref_gutils.get_pointcloud(ptfer, pc2w, prgb, pdepth, paccum, 900)
+    torch.manual_seed(77)
+    perm = torch.randperm(int((pdepth > 0).sum()))
+    out["pc_intr"] = np.array([pintr["fu"], pintr["fv"], pintr["cu"], pintr["cv"]])
+    out["pc_depth"], out["pc_rgb"], out["pc_accum"] = pdepth.numpy(), prgb.numpy(), paccum.numpy()
+    out["pc_c2w"], out["pc_perm"] = pc2w.numpy(), perm.numpy()
+    out["pc_xyz"], out["pc_col"] = xyz.numpy(), col.numpy()
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 

@@ -260,3 +260,121 @@ def test_add_splats_extends_parameters_state_and_records():
     assert float(m.global_scores[3000:].abs().max()) == 0.0
     loss = m.fused_view(cam, intr, gt, w2c[:3, :3].cpu(), 1)    # the grown map still trains
     assert torch.isfinite(loss).all()
+
+
+def _gold():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                "harness_golden.npz"))
+
+
+def test_keyframe_pointcloud_matches_reference_golden():
+    """Against the reference's get_pointcloud run on CPU with the same permutation; float
+    tolerance 1e-5 relative + 1e-6 absolute (its matrix product may sum in another order)."""
+    gold = _gold()
+    fu, fv, cu, cv = [float(v) for v in gold["pc_intr"]]
+    intr = {"fu": fu, "fv": fv, "cu": cu, "cv": cv, "H": 36, "W": 52}
+    t = lambda k: torch.from_numpy(gold[k]).to(DEV)
+    xyz, col = maintenance.keyframe_pointcloud(
+        torch.from_numpy(gold["pc_c2w"]), intr, t("pc_rgb"), t("pc_depth"), t("pc_accum"), 900, 0.6,
+        perm=torch.from_numpy(gold["pc_perm"]))
+    assert xyz.shape == gold["pc_xyz"].shape                    # sample count follows the accum share
+    np.testing.assert_allclose(xyz.cpu().numpy(), gold["pc_xyz"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(col.cpu().numpy(), gold["pc_col"])
+    # first frame: no opacity map, every valid pixel counts
+    xyz0, _ = maintenance.keyframe_pointcloud(
+        torch.from_numpy(gold["pc_c2w"]), intr, t("pc_rgb"), t("pc_depth"), None, 900, 0.6)
+    assert xyz0.shape[0] == 900
+
+
+def test_depth_refresh_matches_reference_expression():
+    H, W = 96, 160
+    g = torch.Generator().manual_seed(5)
+    dsum = torch.rand(H, W, generator=g) * 4
+    alpha = torch.rand(H, W, generator=g)
+    alpha[:10] = 0.0                      # 0/0 -> nan and x/0 -> inf: both count as no depth
+    dsum[:5] = 0.0
+    dsum[40:50, 30:60] = 0.0              # rendered depth 0: the old value stays
+    dense = torch.rand(H, W, generator=g) + 0.1
+    # loop_rectify.py:420-426 with gaussian_base.py:205-209
+    depth = torch.nan_to_num(dsum / alpha, 0, 0)
+    want_dense = dense.clone()
+    want_dense[depth > 0] = depth[depth > 0]
+    want_coarse = want_dense.reshape(H // 8, 8, W // 8, 8).permute(0, 2, 1, 3)[..., 3:5, 3:5] \
+        .reshape(H // 8, W // 8, -1).mean(dim=-1)
+    from vings_mono_amd import _lib
+    L = _lib.lib()
+    d_dense = dense.to(DEV)
+    d_coarse = torch.empty(H // 8, W // 8, device=DEV)
+    a, b = dsum.to(DEV), alpha.to(DEV)
+    _lib.check(L.vings_depth_refresh(H, W, _lib.ptr(a), _lib.ptr(b), _lib.ptr(d_dense),
+                                     _lib.ptr(d_coarse), _lib.stream_ptr(torch.device(DEV))), "refresh")
+    assert torch.equal(d_dense.cpu(), want_dense)
+    torch.testing.assert_close(d_coarse.cpu(), want_coarse, rtol=1e-6, atol=0)
+    with pytest.raises(_lib.VingsError):
+        _lib.check(L.vings_depth_refresh(H - 1, W, _lib.ptr(a), _lib.ptr(b), _lib.ptr(d_dense),
+                                         _lib.ptr(d_coarse), _lib.stream_ptr(torch.device(DEV))), "refresh")
+
+
+def _frame_and_mapper(n=5000, seed=31):
+    dev = torch.device(DEV)
+    W, H = 160, 96
+    raw = synth.make_splats(n, W, H, n_views=2, seed=seed)
+    intr = synth.intrinsic_for(W, H)
+    c2w = synth.window_poses(2)[1].to(dev)
+    w2c = torch.linalg.inv(c2w)
+    gtp = {k: v.to(dev) for k, v in synth.perturb_splats(raw).items()}
+    with torch.no_grad():
+        pr = harness.render(gtp, w2c, intr)
+    return raw, intr, c2w, w2c, pr
+
+
+def test_add_new_frame_prunes_large_and_adds_points():
+    dev = torch.device(DEV)
+    raw, intr, c2w, w2c, pr = _frame_and_mapper()
+    H, W = pr["depth"].shape[-2:]
+    m = harness.SurfelMapper(raw, dev)
+    gt = {"rgb": pr["rgb"].clone(), "depth": pr["depth"].clone(), "depth_cov": torch.ones_like(pr["depth"])}
+    m.fused_view(harness.view_settings(w2c, intr), intr, gt, w2c[:3, :3].cpu(), 0)
+    with torch.no_grad():
+        radii = harness.render({k: v.detach() for k, v in m.params.items()}, w2c, intr)["radii"]
+    n_big = int((radii > 25).sum())
+    gdepth = pr["depth"].clone()
+    gdepth[:, :, :20] = 0.0                                  # no depth there: no new points
+    frame = {"pose": c2w, "depth": gdepth.permute(1, 2, 0), "image": pr["rgb"].permute(1, 2, 0),
+             "intrinsic": intr}
+    n0 = m.n
+    pruned, added = maintenance.add_new_frame(m, frame, accum_thresh=0.5, n_points=2000)
+    assert pruned == n_big
+    assert 0 < added <= 2000 and m.n == n0 - pruned + added
+    assert len(m.optimizer.state) == 0                        # fresh optimiser, as the reference builds
+    new_xyz = m.params["_xyz"].detach()[-added:]
+    # every new point lies on the frame's depth surface: it projects back inside the valid columns
+    cam = (w2c[:3, :3] @ new_xyz.T + w2c[:3, 3:4]).T
+    v = cam[:, 0] / cam[:, 2] * intr["fv"] + intr["cv"]
+    u = cam[:, 1] / cam[:, 2] * intr["fu"] + intr["cu"]
+    assert float(v.min()) >= 19.5 and float(v.max()) <= W - 0.5 and float(u.min()) >= -0.5
+    got_depth = gdepth[0][u.round().long().clamp(0, H - 1), v.round().long().clamp(0, W - 1)]
+    torch.testing.assert_close(cam[:, 2], got_depth, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(torch.sigmoid(m.params["_opacity"].detach()[-added:]),
+                          torch.full((added, 1), 0.8, device=dev))
+    loss = m.fused_view(harness.view_settings(w2c, intr), intr, gt, w2c[:3, :3].cpu(), 1)
+    assert torch.isfinite(loss).all()
+
+
+def test_rectify_tracker_renders_depth_into_tracker_maps():
+    dev = torch.device(DEV)
+    raw, intr, c2w, w2c, pr = _frame_and_mapper(seed=33)
+    H, W = pr["depth"].shape[-2:]
+    m = harness.SurfelMapper(raw, dev)
+    poses = [p.to(dev) for p in synth.window_poses(2)]
+    dense = torch.full((2, H, W), 0.25, device=dev)
+    coarse = torch.zeros((2, H // 8, W // 8), device=dev)
+    maintenance.rectify_tracker(m, poses, intr, dense, coarse)
+    for k, p in enumerate(poses):
+        with torch.no_grad():
+            d = harness.render({kk: v.detach() for kk, v in m.params.items()}, torch.linalg.inv(p), intr)["depth"][0]
+        want = torch.where(d > 0, d, torch.full_like(d, 0.25))
+        assert torch.equal(dense[k], want)
+        wc = want.reshape(H // 8, 8, W // 8, 8).permute(0, 2, 1, 3)[..., 3:5, 3:5].reshape(H // 8, W // 8, -1).mean(-1)
+        torch.testing.assert_close(coarse[k], wc, rtol=1e-6, atol=0)

@@ -63,6 +63,33 @@ __global__ __launch_bounds__(256) void splat_reanchor_kernel(
                     dw * qy - dx * qz + dy * qw + dz * qx, dw * qz + dx * qy - dy * qx + dz * qw);
 }
 
+__device__ __forceinline__ float refreshed_depth(float dsum, float a, float old) {
+    float d = dsum / a;
+    if (isnan(d) || d == INFINITY) d = 0.f;
+    return d > 0.f ? d : old;
+}
+
+// One lane per pixel.  The lane at row/column 3 of an 8x8 block also forms the coarse cell:
+// it recomputes its three neighbours from the inputs, so no lane waits for another's store.
+__global__ __launch_bounds__(256) void depth_refresh_kernel(int H, int W,
+                                                            const float* __restrict__ dsum,
+                                                            const float* __restrict__ alpha,
+                                                            float* __restrict__ dense,
+                                                            float* __restrict__ coarse) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const int p = y * W + x;
+    const float mine = refreshed_depth(dsum[p], alpha[p], dense[p]);
+    if ((x & 7) == 3 && (y & 7) == 3) {
+        const float b = refreshed_depth(dsum[p + 1], alpha[p + 1], dense[p + 1]);
+        const float c = refreshed_depth(dsum[p + W], alpha[p + W], dense[p + W]);
+        const float d = refreshed_depth(dsum[p + W + 1], alpha[p + W + 1], dense[p + W + 1]);
+        coarse[(y >> 3) * (W >> 3) + (x >> 3)] = (mine + b + c + d) / 4.0f;
+    }
+    dense[p] = mine;
+}
+
 }  // namespace vings
 
 using namespace vings;
@@ -92,6 +119,17 @@ extern "C" int vings_splat_reanchor(int N, float* xyz, float* rotation, const in
     splat_reanchor_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(
         N, xyz, rotation, owner_kf, owner_stride, kf_start, kf_end, K, old_w2c, new_c2w,
         delta_quat, scale);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}
+
+extern "C" int vings_depth_refresh(int H, int W, const float* depth_sum, const float* alpha,
+                                   float* dense_map, float* coarse_map, void* stream) {
+    VINGS_REQUIRE(H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, "H and W must be multiples of 8");
+    VINGS_REQUIRE(depth_sum && alpha && dense_map && coarse_map, "null pointer");
+    ProfScope prof(PROF_GLUE, (hipStream_t)stream);
+    depth_refresh_kernel<<<dim3(cdiv(W, 64), cdiv(H, 4)), 256, 0, (hipStream_t)stream>>>(
+        H, W, depth_sum, alpha, dense_map, coarse_map);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }

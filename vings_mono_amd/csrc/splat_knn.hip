@@ -37,6 +37,26 @@ __global__ __launch_bounds__(256) void knn3_mean_dist2_kernel(int N, const float
     if (i < N) out[i] = (b0 + b1 + b2) / 3.0f;
 }
 
+// World position and colour of the chosen pixels of a new keyframe: pixel (row u, column v)
+// with depth z goes to the camera point ((v-cv)/fv*z, (u-cu)/fu*z, z) and through the
+// camera-to-world matrix (tf.py:59-68,46-57 of the reference; gaussian_utils.py:39-46).
+struct Pose34 { float m[12]; };
+
+__global__ __launch_bounds__(256) void keyframe_backproject_kernel(
+        int n, int W, int HW, const int64_t* __restrict__ pixel_ids, const float* __restrict__ depth,
+        const float* __restrict__ rgb, Pose34 c2w, float fu, float fv, float cu, float cv,
+        float* __restrict__ xyz, float* __restrict__ colors) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t pix = pixel_ids[i];
+    const int u = (int)(pix / W), v = (int)(pix % W);
+    const float z = depth[pix];
+    const float x = ((float)v - cv) / fv * z, y = ((float)u - cu) / fu * z;
+    for (int r = 0; r < 3; ++r)
+        xyz[3 * i + r] = c2w.m[4 * r] * x + c2w.m[4 * r + 1] * y + c2w.m[4 * r + 2] * z + c2w.m[4 * r + 3];
+    for (int c = 0; c < 3; ++c) colors[3 * i + c] = rgb[(int64_t)c * HW + pix];
+}
+
 }  // namespace vings
 
 using namespace vings;
@@ -48,6 +68,23 @@ extern "C" int vings_knn3_mean_dist2(int N, const float* xyz, float* mean_dist2,
     VINGS_REQUIRE(xyz && mean_dist2, "null pointer");
     ProfScope prof(PROF_GLUE, (hipStream_t)stream);
     knn3_mean_dist2_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(N, xyz, mean_dist2);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}
+
+extern "C" int vings_keyframe_backproject(int n, int H, int W, const int64_t* pixel_ids,
+                                          const float* depth, const float* rgb,
+                                          const float* c2w_host, float fu, float fv, float cu,
+                                          float cv, float* xyz, float* colors, void* stream) {
+    VINGS_REQUIRE(n >= 0 && H > 0 && W > 0, "sizes");
+    if (n == 0) return VINGS_OK;
+    VINGS_REQUIRE(pixel_ids && depth && rgb && c2w_host && xyz && colors, "null pointer");
+    VINGS_REQUIRE(fu != 0.f && fv != 0.f, "focal length");
+    Pose34 pose;
+    for (int k = 0; k < 12; ++k) pose.m[k] = c2w_host[k];
+    ProfScope prof(PROF_GLUE, (hipStream_t)stream);
+    keyframe_backproject_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(
+        n, W, H * W, pixel_ids, depth, rgb, pose, fu, fv, cu, cv, xyz, colors);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }

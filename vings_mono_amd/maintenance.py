@@ -136,6 +136,114 @@ def new_splat_params(points, colors, rotations, opacity=0.8):
             "_opacity": torch.full((n, 1), logit, dtype=torch.float32, device=points.device)}
 
 
+def keyframe_pointcloud(c2w, intr, gt_rgb, gt_depth, pred_accum, n_points, accum_thresh,
+                        perm=None):
+    """Points a new keyframe contributes (get_pointcloud, gaussian_utils.py:19-54).
+
+    gt_rgb [3,H,W], gt_depth [1,H,W], pred_accum [1,H,W] or None (first frame), all on the
+    device; c2w 4x4.  The number of samples is n_points scaled by the share of valid-depth
+    pixels whose rendered opacity is at most accum_thresh; the samples themselves are drawn
+    from ALL valid-depth pixels, as in the reference.  `perm` (a permutation of the valid
+    pixels, row-major order) replaces the random draw.  Returns (xyz [n,3], colors [n,3])."""
+    L = _lib.lib()
+    _lib.require_gpu_tensor(gt_depth, "gt_depth", torch.float32)
+    _lib.require_gpu_tensor(gt_rgb, "gt_rgb", torch.float32)
+    dev = gt_depth.device
+    H, W = gt_depth.shape[-2:]
+    depth = gt_depth.reshape(H, W).contiguous()
+    rgb = gt_rgb.reshape(3, H, W).contiguous()
+    valid = depth > 0
+    n_all = int(valid.sum())
+    if pred_accum is None:
+        n_open = n_all
+    else:
+        n_open = int((valid & ~(pred_accum.reshape(H, W) > accum_thresh)).sum())
+    n = 0 if n_all == 0 else min(int(n_open / n_all * n_points), n_all)
+    valid_ids = torch.nonzero(depth.reshape(-1)).squeeze(1)            # row-major, int64
+    if perm is None:
+        perm = torch.randperm(valid_ids.shape[0], device=dev)
+    picked = valid_ids[perm.to(dev)[:n]].contiguous()
+    xyz = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    col = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    pose = (ctypes.c_float * 16)(*[float(v) for v in c2w.detach().reshape(-1).tolist()])
+    _lib.check(L.vings_keyframe_backproject(
+        n, H, W, _lib.ptr(picked), _lib.ptr(depth), _lib.ptr(rgb), pose, float(intr["fu"]),
+        float(intr["fv"]), float(intr["cu"]), float(intr["cv"]), _lib.ptr(xyz), _lib.ptr(col),
+        _lib.stream_ptr(dev)), "vings_keyframe_backproject")
+    return xyz, col
+
+
+def add_new_frame(mapper, frame, accum_thresh, n_points=40000, max_radius=25, perm=None,
+                  rotations=None, keep_moments=False):
+    """Map update when a keyframe arrives (gaussian_model.py:92-161): drop the splats this
+    view draws with a radius above max_radius, render again, zero the opacity map where depth
+    or colour disagree with the frame, and add splats back-projected from the frame.
+
+    frame: {'pose' c2w 4x4, 'depth' [H,W,1], 'image' [H,W,3], 'intrinsic' dict}, on the device.
+    The reference's other deletion rule (colour error at the splat's pixel) assigns through a
+    chained advanced index and therefore changes nothing; it is left out.  After the append
+    the reference builds a fresh optimiser (:161), dropping every Adam moment;
+    keep_moments=True keeps the old splats' moments instead.  Returns (n_pruned, n_added)."""
+    from . import harness
+    dev = mapper.device
+    intr = frame["intrinsic"]
+    c2w = frame["pose"].to(dev).float()
+    w2c = torch.linalg.inv(c2w)
+    gt_depth = frame["depth"].to(dev).float().permute(2, 0, 1).contiguous()
+    gt_rgb = frame["image"].to(dev).float().permute(2, 0, 1).contiguous()
+    with torch.no_grad():
+        rets = harness.render({k: v.detach() for k, v in mapper.params.items()}, w2c, intr)
+        first_rgb = rets["rgb"]
+        too_big = rets["radii"] > max_radius
+    n_pruned = int(too_big.sum())
+    if n_pruned:
+        prune(mapper, too_big)
+    with torch.no_grad():
+        rets = harness.render({k: v.detach() for k, v in mapper.params.items()}, w2c, intr)
+        accum = rets["accum"].clone()
+        depth_error = (rets["depth"] - gt_depth).abs()
+        # the colour error is taken against the render made BEFORE the prune (:131 reads pred_rgb of :102)
+        rgb_error = (first_rgb - gt_rgb).abs().sum(dim=0, keepdim=True)
+        accum[depth_error > 10 * depth_error.median()] = 0.0
+        accum[rgb_error > 0.1] = 0.0
+    xyz, col = keyframe_pointcloud(c2w, intr, gt_rgb, gt_depth, accum, n_points, accum_thresh, perm)
+    if rotations is None:
+        rotations = torch.randn((xyz.shape[0], 4), dtype=torch.float32, device=dev)
+    n_added = xyz.shape[0]
+    if n_added >= 4:
+        add_splats(mapper, new_splat_params(xyz, col, rotations[:n_added], opacity=0.8))
+    else:
+        n_added = 0
+    if not keep_moments:
+        mapper.optimizer.state.clear()
+    return n_pruned, n_added
+
+
+def rectify_tracker(mapper, c2w_list, intr, dense_maps, coarse_maps):
+    """Tracker-side refresh after a loop closure (loop_rectify.py:415-426): for every corrected
+    keyframe pose render the depth and fold it into the tracker's stored maps.
+    dense_maps [K,H,W] is updated in place where the rendered depth is positive; coarse_maps
+    [K,H/8,W/8] receives the mean of the four centre pixels of every 8x8 block.  Both live on
+    the device here (the reference keeps them on the host and copies every render back)."""
+    from . import harness
+    L = _lib.lib()
+    dev = mapper.device
+    _lib.require_gpu_tensor(dense_maps, "dense_maps", torch.float32)
+    _lib.require_gpu_tensor(coarse_maps, "coarse_maps", torch.float32)
+    assert dense_maps.is_contiguous() and coarse_maps.is_contiguous()
+    K, H, W = dense_maps.shape
+    assert coarse_maps.shape == (K, H // 8, W // 8) and len(c2w_list) == K
+    with torch.no_grad():
+        params = {k: v.detach() for k, v in mapper.params.items()}
+        for k, c2w in enumerate(c2w_list):
+            w2c = torch.linalg.inv(c2w.to(dev).float())
+            _, _, allmap = harness.render_raw(params, w2c, intr)
+            allmap = allmap.contiguous()
+            _lib.check(L.vings_depth_refresh(H, W, _lib.ptr(allmap[0]), _lib.ptr(allmap[1]),
+                                             _lib.ptr(dense_maps[k]), _lib.ptr(coarse_maps[k]),
+                                             _lib.stream_ptr(dev)), "vings_depth_refresh")
+
+
 def add_splats(mapper, new_params):
     """Append splats to a harness.SurfelMapper: parameters concatenated, Adam moments and
     score records extended with zeros (cat_tensors_to_optimizer gaussian_base.py:74-92,
