@@ -1,9 +1,13 @@
 """CPU checks of the dense-BA oracle (no GPU).
 
-The reference has no tests or golden vectors for this path and its PyTorch twin
-(frontend/geom/ba.py) cannot be imported without lietorch / torch_scatter, so
-parity is unpinned; the oracle is validated against first principles instead.
+The reference has no tests or golden vectors for this path.  Its PyTorch twin of the
+linear solve (frontend/geom/chol.py) does import here, and tests/golden/make_dba_golden.py
+ran it to produce tests/golden/dba_solve_golden.npz: that pins damping, Schur complement,
+Cholesky and back-substitution.  The geometric half (frontend/geom/ba.py, projective_ops.py)
+needs lietorch / torch_scatter, stays unpinned and is validated against first principles.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -191,3 +195,55 @@ def test_corr_index_bilinear_and_adjoint():
     lhs = (O.corr_index_forward(vol, coords, 1) * g).sum()
     rhs = (vol * O.corr_index_backward(vol.shape, coords, g, 1)).sum()
     np.testing.assert_allclose(lhs, rhs, rtol=1e-10)
+
+
+# ---------------------------------------------------------------------------
+# the linear solve against the reference's own solvers (golden vectors)
+# ---------------------------------------------------------------------------
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dba_solve_golden.npz")
+
+
+def _golden_system(g, tag):
+    H, E = g[f"{tag}_H"], g[f"{tag}_E"]
+    return dict(H=H, E=E, C=g[f"{tag}_C"], v=g[f"{tag}_v"], w=g[f"{tag}_w"], P=H.shape[0],
+                M=E.shape[1], HW=E.shape[3])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("name", ["std", "stiff"])
+def test_schur_solve_matches_reference_golden(tag, name):
+    """float64 on both sides; 1e-9 relative to the largest entry."""
+    g = np.load(GOLD)
+    s = _golden_system(g, tag)
+    ep, lm = g[f"{tag}_{name}_eplm"]
+    S, rhs, E, Q = O.reduced_system(s, lm=lm, ep=ep)
+    dx = O.solve_spd(S, rhs)
+    dz = (Q * (s["w"].reshape(-1) - E.T @ dx)).reshape(s["M"], s["HW"])
+    want_dx, want_dz = g[f"{tag}_{name}_dx"], g[f"{tag}_{name}_dz"]
+    np.testing.assert_allclose(dx.reshape(-1, 6), want_dx, rtol=0, atol=1e-9 * np.abs(want_dx).max())
+    np.testing.assert_allclose(dz, want_dz, rtol=0, atol=1e-9 * np.abs(want_dz).max())
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_motion_only_solve_and_the_twin_damping(tag):
+    """The twin's block_solve (chol.py:32-43) multiplies its damping by a 6x6 identity that
+    broadcasts over EVERY pose block, so off-diagonal blocks get ep + lm*H on their diagonals
+    too.  The compiled extension the reference actually calls damps the diagonal of the
+    assembled matrix, which is what the oracle does; with the twin's damping the oracle's
+    solver reproduces the golden vector, which pins the factorisation itself."""
+    g = np.load(GOLD)
+    s = _golden_system(g, tag)
+    P = s["P"]
+    Hb = s["H"].copy()
+    idx = np.arange(6)
+    Hb[:, :, idx, idx] += 0.1 + 1e-4 * Hb[:, :, idx, idx]
+    H = Hb.transpose(0, 2, 1, 3).reshape(6 * P, 6 * P)
+    dx = O.solve_spd(H, s["v"].reshape(-1)).reshape(P, 6)
+    want = g[f"{tag}_motion_dx"]
+    np.testing.assert_allclose(dx, want, rtol=0, atol=1e-9 * np.abs(want).max())
+
+
+def test_failed_factorisation_returns_zero_like_the_reference():
+    g = np.load(GOLD)
+    assert not g["bad_dx"].any()
+    assert not O.solve_spd(-np.eye(12), np.ones(12)).any()
