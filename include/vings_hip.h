@@ -403,6 +403,47 @@ int vings_corr_index_forward(const void* volume, const float* coords, void* corr
 int vings_corr_index_backward(const float* coords, const void* corr_grad, void* volume_grad, int E,
                               int h1, int w1, int h2, int w2, int r, int half, void* stream);
 
+/* ========================================================================
+ * Tracker -> mapper packaging.
+ * ======================================================================== */
+
+/* compute_covariances (depth_video.py:676-726).  For depth variable k (frame kx[k]) and
+ * pixel p:  e = the 6P coupling rows selected by block_of[K,P] (row block of E[(P+E),6,HW]
+ * as vings_dba_export lays it out, -1 = zero block), F = (Q[k,p] e)^T L_inv with
+ * L_inv[6P,6P] the inverse of the lower Cholesky factor of the reduced camera matrix
+ * (row major, device), and depths_cov[kx[k],p] = (Q + |F|^2) / (disps[kx[k],p]^4 + 1e-6).
+ * Q[K,HW]; disps, depths_cov [B,ht,wd]; kx[K] int64 (device).  P <= 20. */
+int vings_depth_covariance(int ht, int wd, int P, int K, const float* Q, const float* E,
+                           const int32_t* block_of, const float* L_inv, const float* disps,
+                           const int64_t* kx, float* depths_cov, void* stream);
+
+/* cvx_upsample (droid_net.py:17-38) as DepthVideo.upsample applies it (depth_video.py:236-243):
+ * for the K frames ix[k] (int64, device) every coarse cell of src[f][B,ht,wd] becomes an 8x8
+ * patch of dst[f][B,8ht,8wd], each output the softmax(mask[k, 0..8, i, j, y, x])-weighted sum
+ * of the cell's 3x3 neighbourhood (zero padded); mask[K,576,ht,wd] float32, channel
+ * (n*8+i)*8+j.  n_fields (1..4) maps share one pass over the mask; src_host / dst_host are
+ * host arrays of device pointers; dst pointers 16-byte aligned. */
+int vings_upsample_maps(int K, int ht, int wd, const int64_t* ix, const float* mask, int n_fields,
+                        const float* const* src_host, float* const* dst_host, void* stream);
+
+/* judge_and_package_v3, the array work (middleware_utils.py:224-238): for the n frames
+ * frame_ids[n] (int64, device) of images[B,3,H,W] uint8, disps_up[B,H,W], depths_cov_up[B,H,W]:
+ *   cov_median[f] = median of the frame's covariance map (mean of the two middle values for
+ *                   an even count, like numpy.median);
+ *   depths[n,H,W]  = 1/(disps_up+1e-6), 0 where that exceeds max_depth or the covariance
+ *                   exceeds cov_times * cov_median[f];
+ *   rgbs[n,H,W,3]  = images/255, 0 where depths == 0;
+ *   depths_cov[n,H,W] = the covariance, replaced where depths == 0 by the largest covariance
+ *                   of any pixel (all frames) that kept a positive depth (NaN if none did;
+ *                   the reference raises there).
+ * The maps must not hold NaN.  No host synchronisation. */
+size_t vings_package_workspace_bytes(int n_frames);
+int vings_package_keyframes(int n_frames, int H, int W, const int64_t* frame_ids,
+                            const uint8_t* images, const float* disps_up,
+                            const float* depths_cov_up, float max_depth, float cov_times,
+                            float* rgbs, float* depths, float* depths_cov, float* cov_median,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * Optional per-kernel timing with HIP events on the caller's stream (no
  * counterpart in the reference, whose only timers are the wandb brackets of
