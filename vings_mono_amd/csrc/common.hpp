@@ -47,6 +47,14 @@ struct ProfScope {
     ~ProfScope() { if (on) prof_end(tag, s); }
 };
 
+// Workgroups are dealt round-robin over the 8 XCDs, each with its own L2, so blocks b and b+8
+// share one.  This bijection hands every such group one contiguous run of the n work items
+// (neighbouring image tiles, which read the same splat records, then meet in one L2).
+__device__ __forceinline__ int xcd_contiguous(int b, int n) {
+    const int q = n >> 3, r = n & 7, g = b & 7;
+    return (g < r ? g * (q + 1) : r * (q + 1) + (g - r) * q) + (b >> 3);
+}
+
 // ---- wave64 primitives -----------------------------------------------------
 constexpr int kWave = 64;
 

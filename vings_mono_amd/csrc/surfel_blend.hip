@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(
     float* __restrict__ allmap, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
     __shared__ float4 rec[kBatch * (kRec4 - 1)];
     __shared__ unsigned long long hit[16];
-    const int tile = blockIdx.x;
+    const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
     const int tx = tile % gx, ty = tile / gx;
     // wave w renders block (w & 1, w >> 1) of the tile; lane l is pixel (l & 7, l >> 3) of it
     const int px = tx * 16 + kBlk * ((threadIdx.x >> 6) & 1) + (threadIdx.x & 7);
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void blend_importance_kernel(
     __shared__ float acc[kBatch];
     __shared__ uint32_t ids[kBatch];
     __shared__ uint32_t wmaxs[4];
-    const int tile = blockIdx.x;
+    const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
     const int tx = tile % gx, ty = tile / gx;
     const int px = tx * 16 + kBlk * ((threadIdx.x >> 6) & 1) + (threadIdx.x & 7);
     const int py = ty * 16 + kBlk * (threadIdx.x >> 7) + ((threadIdx.x >> 3) & 7);
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256, 5) void blend_bwd_kernel(
     __shared__ uint32_t ids[kBatchBwd];
     __shared__ unsigned long long hit[16];
     __shared__ uint32_t wmax[4];
-    const int tile = blockIdx.x;
+    const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
     const int tx = tile % gx, ty = tile / gx;
     // wave w renders block (w & 1, w >> 1) of the tile; lane l is pixel (l & 7, l >> 3) of it
     const int px = tx * 16 + kBlk * ((threadIdx.x >> 6) & 1) + (threadIdx.x & 7);
