@@ -29,6 +29,10 @@ __global__ __launch_bounds__(256) void mix_kernel(float* out, int iters, float a
 #pragma unroll
     for (int c = 0; c < 8; ++c) v[c] = threadIdx.x * 0.001f + c;
     const float sa = __builtin_amdgcn_readfirstlane(a), sb = __builtin_amdgcn_readfirstlane(b);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 w2[4], k2 = {a, b};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w2[c] = f2{v[2 * c], v[2 * c + 1]};
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -47,13 +51,17 @@ __global__ __launch_bounds__(256) void mix_kernel(float* out, int iters, float a
                 }
                 if (KIND == 5) asm volatile("v_rcp_f32 %0, %0" : "+v"(v[c]));
                 if (KIND == 6) asm volatile("v_exp_f32 %0, %0" : "+v"(v[c]));
-                if (KIND == 7) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(*(double*)&v[c & 6]) : "v"(*(double*)&v[(c & 6)]));
+                if (KIND == 7 && c < 4) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(w2[c]) : "v"(k2));
+                if (KIND == 8 && c < 4) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(w2[c]) : "v"(k2));
+                if (KIND == 9 && c < 4) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(w2[c]) : "v"(k2));
             }
         }
     }
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) s += v[c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s += w2[c].x + w2[c].y;
     if (s == 12345.678f) out[0] = s + sb;
 }
 
@@ -68,7 +76,7 @@ static void run_mix(const char* name, int waves_per_simd, float* out, double ghz
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const double n = (double)waves_per_simd * iters * 64 * (KIND == 3 ? 2 : 1);
+    const double n = (double)waves_per_simd * iters * 64 * (KIND == 3 ? 2.0 : KIND >= 7 ? 0.5 : 1.0);
     printf("%-28s waves/SIMD=%d  %.2f cycles per wave-instruction per SIMD\n", name, waves_per_simd,
            ms * 1e-3 * ghz * 1e9 / n);
 }
@@ -106,6 +114,9 @@ int main() {
         run_mix<4>("v_permlane32_swap", w, out, ghz);
         run_mix<5>("v_rcp_f32", w, out, ghz);
         run_mix<6>("v_exp_f32", w, out, ghz);
+        run_mix<7>("v_pk_fma_f32", w, out, ghz);
+        run_mix<8>("v_pk_mul_f32", w, out, ghz);
+        run_mix<9>("v_pk_add_f32", w, out, ghz);
     }
     hipFree(out);
     return 0;
