@@ -242,7 +242,7 @@ struct HitWalk {
     }
 };
 
-__global__ __launch_bounds__(256) void blend_fwd_kernel(
+__global__ __launch_bounds__(256, 5) void blend_fwd_kernel(
     int H, int W, int gx, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ vals,
     const float* __restrict__ geom, const float* __restrict__ bg,
     const uint8_t* __restrict__ pixel_mask, float* __restrict__ out_color,
