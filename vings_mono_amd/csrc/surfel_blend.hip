@@ -37,7 +37,7 @@ constexpr int kBatch = 256;
 // backward batch: 192 records keep the kernel at 31.6 KB of LDS, i.e. five workgroups per
 // CU (160 KB) instead of three with 256; its launch bound asks for 5 waves per SIMD (96
 // VGPRs: the staging code spills a little, the blend loop does not)
-constexpr int kBatchBwd = 192;
+constexpr int kBatchBwd = 160;
 constexpr int kRec4 = VINGS_GEOM_STRIDE / 4;  // float4 per record
 constexpr int kGrad = VINGS_GRAD_STRIDE;      // gradient components per splat
 
@@ -242,7 +242,7 @@ struct HitWalk {
     }
 };
 
-__global__ __launch_bounds__(256, 5) void blend_fwd_kernel(
+__global__ __launch_bounds__(256, 6) void blend_fwd_kernel(
     int H, int W, int gx, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ vals,
     const float* __restrict__ geom, const float* __restrict__ bg,
     const uint8_t* __restrict__ pixel_mask, float* __restrict__ out_color,
@@ -273,35 +273,42 @@ __global__ __launch_bounds__(256, 5) void blend_fwd_kernel(
         stage_batch(rec, hit, geom, vals, base + threadIdx.x, r1, nullptr, (float)(tx * 16),
                     (float)(ty * 16));
         __syncthreads();
-        HitWalk walk;
-        walk.begin_forward(hit, wv);
-        int j;
-        // no software prefetch here: the forward kernel is light on registers, so 6-7
-        // resident waves per SIMD hide the LDS latency better than a second record would
-        while (walk.next_forward(j)) {
-            if (__ballot(!done) == 0ull) break;  // every pixel of this wave has saturated
-            const uint32_t contributor = (base - r0) + (uint32_t)j + 1u;  // 1-based position
-            const Splat s = unpack(load_rec(rec + j * (kRec4 - 1)));
-            Hit h;
-            bool c = eval_hit(s, fx, fy, h) & !done;
-            const float test_T = T * (1.f - h.alpha);
-            const bool sat = c & (test_T < kTMin);
-            done |= sat;
-            c &= !sat;
-            if (c) {  // the only divergent region: accumulators update in place
-                const float w = h.alpha * T;
+        // the four ballot words of this wave's block (one per loader wave), front to back; two
+        // plain nested loops keep the sixteen accumulators in place (an iterator object with
+        // the word index in its state made the compiler copy all of them once per splat)
+        for (int lw = 0; lw < 4; ++lw) {
+            unsigned long long m = uniform_u64(hit[lw * 4 + wv]);
+            while (m != 0ull) {
+                if (__ballot(!done) == 0ull) break;  // every pixel of this wave has saturated
+                const int j = lw * 64 + __builtin_ctzll(m);
+                m &= m - 1ull;
+                const uint32_t contributor = (base - r0) + (uint32_t)j + 1u;  // 1-based position
+                const Splat s = unpack(load_rec(rec + j * (kRec4 - 1)));
+                Hit h;
+                bool c = eval_hit(s, fx, fy, h) & !done;
+                const float test_T = T * (1.f - h.alpha);
+                const bool sat = c & (test_T < kTMin);
+                done |= sat;
+                c &= !sat;
+                // No branch from here on, not even a wave-uniform skip of splats that touch no
+                // pixel: every lane runs the same instructions and idle lanes add exact zeros
+                // through w = 0 (their depth is replaced by 1 so that every term stays finite).
+                const float w = c ? h.alpha * T : 0.f;
+                const float depth = c ? h.depth : 1.f;
                 const float A = 1.f - T;
-                const float m = c1 * (1.f - kNearN * rcp_fast(h.depth));
-                dist += (m * m * A + M2 - 2.f * m * M1) * w;
-                Dd += h.depth * w;
-                M1 += m * w;
-                M2 += m * m * w;
-                if (T > 0.5f) { med = h.depth; medc = contributor; }
+                const float m1 = c1 * (1.f - kNearN * rcp_fast(depth));
+                dist += (m1 * m1 * A + M2 - 2.f * m1 * M1) * w;
+                Dd += depth * w;
+                M1 += m1 * w;
+                M2 += m1 * m1 * w;
+                const bool md = c & (T > 0.5f);
+                med = md ? depth : med;
+                medc = md ? contributor : medc;
                 N0 += s.n[0] * w; N1 += s.n[1] * w; N2 += s.n[2] * w;
                 C0 += s.rgb[0] * w; C1 += s.rgb[1] * w; C2 += s.rgb[2] * w;
                 F0 += s.fl[0] * w; F1 += s.fl[1] * w;
-                T = test_T;
-                last = contributor;
+                T = c ? test_T : T;
+                last = c ? contributor : last;
             }
         }
     }
@@ -343,7 +350,7 @@ __device__ __forceinline__ float half_row_sum(float v) {
 // (/root/reference/scripts/gaussian/gaussian_model.py:233-241,
 //  /root/reference/scripts/loop/loop_model.py:185-186); here no image is written and no
 // backward pass runs.  Same walk as blend_fwd_kernel; one wave sum per (wave, splat).
-__global__ __launch_bounds__(256) void blend_importance_kernel(
+__global__ __launch_bounds__(256, 6) void blend_importance_kernel(
     int H, int W, int gx, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ vals,
     const float* __restrict__ geom, const uint8_t* __restrict__ pixel_mask,
     float* __restrict__ importance, const float* __restrict__ bg,
@@ -438,7 +445,7 @@ __device__ __forceinline__ void row_mirror_add5(float& a, float& b, float& c, fl
         : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
 }
 
-__global__ __launch_bounds__(256, 5) void blend_bwd_kernel(
+__global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
     int H, int W, int gx, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ vals,
     const float* __restrict__ geom, const float* __restrict__ bg,
     const uint8_t* __restrict__ pixel_mask, const float* __restrict__ final_T,
