@@ -210,38 +210,6 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// Scalar walk over the set bits of a wave's four ballots.
-struct HitWalk {
-    const unsigned long long* hit;
-    int strip, lw;
-    unsigned long long m;
-    __device__ __forceinline__ void begin_forward(const unsigned long long* h, int s) {
-        hit = h; strip = s; lw = 0; m = uniform_u64(h[s]);
-    }
-    __device__ __forceinline__ bool next_forward(int& j) {
-        while (m == 0ull) {
-            if (++lw > 3) return false;
-            m = uniform_u64(hit[lw * 4 + strip]);
-        }
-        j = lw * 64 + __builtin_ctzll(m);
-        m &= m - 1ull;
-        return true;
-    }
-    __device__ __forceinline__ void begin_backward(const unsigned long long* h, int s) {
-        hit = h; strip = s; lw = 3; m = uniform_u64(h[12 + s]);
-    }
-    __device__ __forceinline__ bool next_backward(int& j) {
-        while (m == 0ull) {
-            if (--lw < 0) return false;
-            m = uniform_u64(hit[lw * 4 + strip]);
-        }
-        const int bit = 63 - __builtin_clzll(m);
-        j = lw * 64 + bit;
-        m &= ~(1ull << bit);
-        return true;
-    }
-};
-
 __global__ __launch_bounds__(256, 6) void blend_fwd_kernel(
     int H, int W, int gx, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ vals,
     const float* __restrict__ geom, const float* __restrict__ bg,
@@ -377,27 +345,29 @@ __global__ __launch_bounds__(256, 6) void blend_importance_kernel(
                     (float)(ty * 16));
         acc[threadIdx.x] = 0.f;
         __syncthreads();
-        HitWalk walk;
-        walk.begin_forward(hit, wv);
-        int j;
-        while (walk.next_forward(j)) {
-            if (__ballot(!done) == 0ull) break;
-            const Splat s = unpack(load_rec(rec + j * (kRec4 - 1)));
-            Hit h;
-            bool c = eval_hit(s, fx, fy, h) & !done;
-            const float test_T = T * (1.f - h.alpha);
-            const bool sat = c & (test_T < kTMin);
-            done |= sat;
-            c &= !sat;
-            if (__ballot(c) == 0ull) continue;
-            float w = c ? h.alpha * T : 0.f;
-            T = c ? test_T : T;
-            if (rgb_max_bits) { C0 += s.rgb[0] * w; C1 += s.rgb[1] * w; C2 += s.rgb[2] * w; }
-            w = half_row_sum(w);
-            w += dpp_f<0x140>(w);          // row_mirror: sum of the 16-lane row
-            w = swap16_add(w, w);
-            w = swap32_add(w, w);
-            if (lane == 0) atomicAdd(&acc[j], w);
+        for (int lw = 0; lw < 4; ++lw) {
+            unsigned long long m = uniform_u64(hit[lw * 4 + wv]);
+            while (m != 0ull) {
+                if (__ballot(!done) == 0ull) break;
+                const int j = lw * 64 + __builtin_ctzll(m);
+                m &= m - 1ull;
+                const Splat s = unpack(load_rec(rec + j * (kRec4 - 1)));
+                Hit h;
+                bool c = eval_hit(s, fx, fy, h) & !done;
+                const float test_T = T * (1.f - h.alpha);
+                const bool sat = c & (test_T < kTMin);
+                done |= sat;
+                c &= !sat;
+                if (__ballot(c) == 0ull) continue;
+                float w = c ? h.alpha * T : 0.f;
+                T = c ? test_T : T;
+                if (rgb_max_bits) { C0 += s.rgb[0] * w; C1 += s.rgb[1] * w; C2 += s.rgb[2] * w; }
+                w = half_row_sum(w);
+                w += dpp_f<0x140>(w);          // row_mirror: sum of the 16-lane row
+                w = swap16_add(w, w);
+                w = swap32_add(w, w);
+                if (lane == 0) atomicAdd(&acc[j], w);
+            }
         }
         __syncthreads();
         const uint32_t n = min((uint32_t)kBatch, r1 - base);
@@ -516,10 +486,14 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
                     (float)(tx * 16), (float)(ty * 16));
         for (int k = threadIdx.x; k < cnt * kGrad; k += 256) acc[k] = 0.f;
         __syncthreads();
-        HitWalk walk;
-        walk.begin_backward(hit, wv);
-        int j;
-        while (walk.next_backward(j)) {
+        // the four ballot words of this wave's block, back to front (plain nested loops: see
+        // blend_fwd_kernel)
+        for (int lw = 3; lw >= 0; --lw) {
+          unsigned long long wm = uniform_u64(hit[lw * 4 + wv]);
+          while (wm != 0ull) {
+            const int bit = 63 - __builtin_clzll(wm);
+            const int j = lw * 64 + bit;
+            wm &= ~(1ull << bit);
             const uint32_t pos = bstart + j;
             const Splat s = unpack(load_rec(rec + j * (kRec4 - 1)));
             Hit h;
@@ -605,6 +579,7 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
                         if (u5[k] != 0.f) atomicAdd(&acc[j * kGrad + 4 * k + comp0], u5[k]);
                 }
             }
+          }
         }
         __syncthreads();
         // flush: consecutive lanes write consecutive floats of the accumulator
