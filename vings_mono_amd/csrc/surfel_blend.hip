@@ -488,6 +488,7 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
         __syncthreads();
         // the four ballot words of this wave's block, back to front (plain nested loops: see
         // blend_fwd_kernel)
+#pragma unroll
         for (int lw = 3; lw >= 0; --lw) {
           unsigned long long wm = uniform_u64(hit[lw * 4 + wv]);
           while (wm != 0ull) {
@@ -573,10 +574,11 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
                 row_mirror_add5(u5[0], u5[1], u5[2], u5[3], u5[4]);
                 const int row = lane >> 4;
                 const int comp0 = ((row & 1) << 1) | (row >> 1);
+                // unconditional: testing each sum for zero costs more than adding one
                 if ((lane & 15) == 0) {
 #pragma unroll
                     for (int k = 0; k < kGrad / 4; ++k)
-                        if (u5[k] != 0.f) atomicAdd(&acc[j * kGrad + 4 * k + comp0], u5[k]);
+                        atomicAdd(&acc[j * kGrad + 4 * k + comp0], u5[k]);
                 }
             }
           }
