@@ -557,16 +557,32 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
             g[9] = a2 * h.dx;
             g[10] = a2 * h.dy;
             {
-                // Transposing reduction.  v_permlane32_swap exchanges the upper half of one
-                // register with the lower half of another, so swap + add sums a PAIR of
-                // components over lanes l / l+32 and leaves one component per half;
-                // v_permlane16_swap does the same for odd/even 16-lane rows.  After the two
-                // steps 20 components have become 5 registers whose four rows hold different
-                // components (row r, register k -> component 4k + {0,2,1,3}[r]), each already
-                // summed over the four rows; a DPP row sum finishes them.
+                // Transposing reduction.  Step 1 sums a PAIR of components over lanes l / l+32
+                // and leaves one component per half: each lane keeps the component its half
+                // will own and fetches the partner's share of it.  Step 2 (v_permlane16_swap +
+                // add) does the same for odd/even 16-lane rows.  After the two steps 20
+                // components have become 5 registers whose four rows hold different components
+                // (row r, register k -> component 4k + {0,2,1,3}[r]), each already summed over
+                // the four rows; a DPP row sum finishes them.
+                // Step 1 goes through ds_bpermute: the LDS crossbar is idle here, while
+                // v_permlane32_swap occupies the vector issue port for 10-12 cycles; the ten
+                // exchanges are independent, so their latency overlaps.  (Step 2 through
+                // the crossbar as well would put a second LDS round trip on the critical path
+                // and measures slower.)
                 float v10[kGrad / 2];
+                {
+                    const bool lo = lane < 32;
+                    const int partner = (lane ^ 32) << 2;
+                    float mine[kGrad / 2], theirs[kGrad / 2];
 #pragma unroll
-                for (int i = 0; i < kGrad / 2; ++i) v10[i] = swap32_add(g[2 * i], g[2 * i + 1]);
+                    for (int i = 0; i < kGrad / 2; ++i) {
+                        mine[i] = lo ? g[2 * i] : g[2 * i + 1];
+                        theirs[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(
+                            partner, __builtin_bit_cast(int, lo ? g[2 * i + 1] : g[2 * i])));
+                    }
+#pragma unroll
+                    for (int i = 0; i < kGrad / 2; ++i) v10[i] = mine[i] + theirs[i];
+                }
                 float u5[kGrad / 4];
 #pragma unroll
                 for (int k = 0; k < kGrad / 4; ++k)
