@@ -446,6 +446,7 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, o, 64));
     if (lane == 0) wmax[wv] = mx;
+    const uint32_t wave_last = __builtin_amdgcn_readfirstlane(mx);
     __syncthreads();
     const uint32_t maxlast = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
     if (maxlast == 0) return;
@@ -491,6 +492,10 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
 #pragma unroll
         for (int lw = 3; lw >= 0; --lw) {
           unsigned long long wm = uniform_u64(hit[lw * 4 + wv]);
+          // records behind the deepest contributor of this wave's own block touch nothing here
+          const int lim = (int)wave_last - (int)bstart - lw * 64;
+          if (lim <= 0) continue;
+          if (lim < 64) wm &= (1ull << lim) - 1ull;
           while (wm != 0ull) {
             const int bit = 63 - __builtin_clzll(wm);
             const int j = lw * 64 + bit;
