@@ -452,6 +452,9 @@ int vings_package_keyframes(int n_frames, int H, int W, const int64_t* frame_ids
  * recorded events and returns the summed milliseconds / launch count of a tag.
  */
 int vings_profile_enable(int on);
+/* Restricts the timing to the tags whose bit is set (bit t = tag t; default all): every timed
+ * launch costs two event records on the stream, a few microseconds each. */
+int vings_profile_select(uint32_t tag_mask);
 int vings_profile_num_tags(void);
 const char* vings_profile_tag_name(int tag);
 int vings_profile_read(int tag, double* total_ms, int64_t* count);

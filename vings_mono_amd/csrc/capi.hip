@@ -32,6 +32,7 @@ std::mutex g_mu;
 std::vector<Pair> g_pairs;      // pool
 size_t g_used = 0;
 bool g_on = false;
+uint32_t g_mask = ~0u;          // tags that are timed while g_on
 int g_open[PROF_NTAGS];
 const char* kTagNames[PROF_NTAGS] = {"project_fwd", "bin", "blend_fwd", "blend_bwd",
                                      "project_bwd", "adam", "dba_jacobian", "dba_schur",
@@ -43,7 +44,7 @@ bool prof_enabled() { return g_on; }
 
 void prof_begin(int tag, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_on || g_used >= g_pairs.size()) { g_open[tag] = -1; return; }
+    if (!g_on || !((g_mask >> tag) & 1u) || g_used >= g_pairs.size()) { g_open[tag] = -1; return; }
     Pair& p = g_pairs[g_used];
     p.tag = tag; p.closed = false;
     if (hipEventRecord(p.a, s) != hipSuccess) { g_open[tag] = -1; return; }
@@ -73,6 +74,12 @@ extern "C" int vings_profile_enable(int on) {
     for (int t = 0; t < PROF_NTAGS; ++t) g_open[t] = -1;
     g_used = 0;
     g_on = on != 0;
+    return VINGS_OK;
+}
+
+extern "C" int vings_profile_select(uint32_t tag_mask) {
+    std::lock_guard<std::mutex> lk(vings::g_mu);
+    vings::g_mask = tag_mask;
     return VINGS_OK;
 }
 

@@ -24,6 +24,20 @@ def enable(on=True):
     _lib.check(en(1 if on else 0), "vings_profile_enable")
 
 
+def select(tags=None):
+    """Time only the named tags (None = all); each timed launch costs two event records."""
+    _, _, nt, nm, _ = _fns()
+    sel = _lib.bind("vings_profile_select", ctypes.c_int, [ctypes.c_uint32])
+    if tags is None:
+        mask = 0xFFFFFFFF
+    else:
+        names = [nm(t).decode() for t in range(nt())]
+        mask = 0
+        for t in tags:
+            mask |= 1 << names.index(t)
+    _lib.check(sel(mask), "vings_profile_select")
+
+
 def read():
     """{tag: {"ms": total milliseconds, "count": launches}} for every tag that ran."""
     _, _, nt, nm, rd = _fns()
