@@ -14,9 +14,13 @@
  *   - every pointer is a DEVICE pointer unless the name ends in _host
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream)
  *   - tensors are dense, row-major, float32 unless stated
- *   - the caller owns all memory, including workspaces; no entry point
- *     allocates; only vings_surfel_project synchronises (it returns the
- *     instance count the caller needs to size the sort buffers)
+ *   - the caller owns all device memory, including workspaces; no entry point
+ *     allocates device memory.  The library itself owns two small host-side
+ *     things, both created at first use and kept: a 64-byte pinned mailbox per
+ *     GPU (vings_surfel_project) and the event pool of vings_profile_enable
+ *   - vings_surfel_project and vings_splat_compact_plan synchronise with the
+ *     host (each returns a count the caller needs to size buffers); everything
+ *     else is asynchronous on the given stream
  *   - return value 0 = success, negative = vings_status
  */
 #ifndef VINGS_HIP_H

@@ -8,6 +8,8 @@
 //
 // Serves GaussianRasterizer.forward/backward as called at
 // /root/reference/scripts/gaussian/gaussian_base.py:193-203,382.
+#include <mutex>
+
 #include "common.hpp"
 
 namespace vings {
@@ -212,7 +214,8 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
 }
 
 // Single workgroup: in-place exclusive scan of block_counts[0..nb), total in [nb].
-__global__ __launch_bounds__(1024) void scan_blocks_kernel(uint32_t* __restrict__ counts, int nb) {
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(uint32_t* __restrict__ counts, int nb,
+                                                           uint32_t* __restrict__ host_tail) {
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
     if (threadIdx.x == 0) carry_s = 0;
@@ -251,6 +254,9 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(uint32_t* __restrict_
         for (int k = 1; k < 16; ++k) { lo = min(lo, rlo[k]); hi = max(hi, rhi[k]); }
         counts[nb] = carry_s;
         counts[3 * nb + 1] = lo; counts[3 * nb + 2] = hi; counts[3 * nb + 3] = carry_s;
+        // the same three words straight into pinned host memory: the host reads them after
+        // the stream has drained, without a copy command in between
+        host_tail[0] = lo; host_tail[1] = hi; host_tail[2] = carry_s;
     }
 }
 
@@ -339,6 +345,15 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
     if (scores) reinterpret_cast<float2*>(scores)[i] = make_float2(sc[0], sc[1]);
 }
 
+// One 64-byte pinned, device-visible host buffer per GPU, created at the first projection call
+// on that GPU and kept for the life of the process (the only memory this library owns besides
+// the optional event pool).  A pageable device-to-host copy costs ~50 us more per view.
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_mail_mu[kMaxDevices];
+uint32_t* g_mail[kMaxDevices] = {};
+}  // namespace
+
 }  // namespace vings
 
 using namespace vings;
@@ -371,12 +386,16 @@ extern "C" int vings_surfel_project(int N, int H, int W, float scale_modifier,
                                           depth, radii, rect, tiles_touched, block_prefix,
                                           block_prefix + nb + 1, block_prefix + 2 * nb + 1);
     VINGS_LAUNCH_CHECK();
-    scan_blocks_kernel<<<1, 1024, 0, s>>>(block_prefix, nb);
-    VINGS_LAUNCH_CHECK();
     }
-    uint32_t tail[3] = {0, 0, 0};   // depth-bit min, max, instance total
-    VINGS_CHECK_HIP(hipMemcpyAsync(tail, block_prefix + 3 * nb + 1, sizeof(tail),
-                                   hipMemcpyDeviceToHost, s));
+    int dev = 0;
+    VINGS_CHECK_HIP(hipGetDevice(&dev));
+    VINGS_REQUIRE(dev >= 0 && dev < kMaxDevices, "device index");
+    // held until the words are read: calls on one GPU share its mailbox
+    std::lock_guard<std::mutex> lk(g_mail_mu[dev]);
+    if (!g_mail[dev]) VINGS_CHECK_HIP(hipHostMalloc((void**)&g_mail[dev], 64, hipHostMallocDefault));
+    volatile uint32_t* tail = g_mail[dev];   // depth-bit min, max, instance total
+    scan_blocks_kernel<<<1, 1024, 0, s>>>(block_prefix, nb, g_mail[dev]);
+    VINGS_LAUNCH_CHECK();
     VINGS_CHECK_HIP(hipStreamSynchronize(s));
     *num_instances_host = (int64_t)tail[2];
     if (depth_bits_range_host && tail[2] > 0) {

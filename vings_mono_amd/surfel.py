@@ -80,6 +80,9 @@ def view_importance(means3D, colors, opacities, scales, rotations, settings, out
     return out, st.radii
 
 
+_D_HINT = {}   # device index -> instance count of the latest forward pass
+
+
 def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys, blend):
     L = _lib.lib()
     dev = means3D.device
@@ -109,6 +112,19 @@ def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys,
     st.rect = torch.empty((max(N, 1), 4), dtype=torch.int32, device=dev)
     st.tiles_touched = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
     st.block_prefix = torch.empty(3 * nb + 4, dtype=torch.int32, device=dev)
+    T = ((W + TILE - 1) // TILE) * ((H + TILE - 1) // TILE)
+    st.ranges = torch.empty((T, 2), dtype=torch.int32, device=dev)
+    # The projection call returns the instance count D to the host, and the GPU idles until the
+    # sort is launched.  Buffers sized from the previous view's count (plus 1/8) are therefore
+    # allocated BEFORE that call, so that nothing but the launch sits in the gap.
+    hint = _D_HINT.get(dev.index, 0)
+    pre = None
+    if hint > 0:
+        cap = hint + hint // 8 + 4096
+        cap_ws = int(L.vings_surfel_bin_workspace_bytes(cap))
+        pre = (cap, torch.empty(cap, dtype=torch.int64, device=dev),
+               torch.empty(cap, dtype=torch.int32, device=dev),
+               torch.empty(cap_ws + 256, dtype=torch.uint8, device=dev), cap_ws)
     d_host = ctypes.c_int64(0)
     d_range = (ctypes.c_uint32 * 2)(0, 0xFFFFFFFF)
     check(L.vings_surfel_project(
@@ -120,12 +136,14 @@ def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys,
     st.D = D
     global LAST_INSTANCE_COUNT
     LAST_INSTANCE_COUNT = D
-    T = ((W + TILE - 1) // TILE) * ((H + TILE - 1) // TILE)
-    st.keys = torch.empty(max(D, 1), dtype=torch.int64, device=dev)
-    st.vals = torch.empty(max(D, 1), dtype=torch.int32, device=dev)
-    st.ranges = torch.empty((T, 2), dtype=torch.int32, device=dev)
-    ws_bytes = int(L.vings_surfel_bin_workspace_bytes(D))
-    ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
+    _D_HINT[dev.index] = D
+    if pre is not None and D <= pre[0]:
+        _, st.keys, st.vals, ws, ws_bytes = pre      # longer than D: entries [D:] are unused
+    else:
+        st.keys = torch.empty(max(D, 1), dtype=torch.int64, device=dev)
+        st.vals = torch.empty(max(D, 1), dtype=torch.int32, device=dev)
+        ws_bytes = int(L.vings_surfel_bin_workspace_bytes(D))
+        ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
     ws_ptr = (ws.data_ptr() + 255) & ~255
     check(L.vings_surfel_bin(N, H, W, D, int(d_range[0]), int(d_range[1]), ptr(st.depth),
                              ptr(st.rect), ptr(st.tiles_touched),
