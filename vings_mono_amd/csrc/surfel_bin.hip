@@ -32,9 +32,13 @@ constexpr int kMaxPasses = 8;
 __global__ __launch_bounds__(256) void emit_keys_kernel(
     int N, int gx, const float* __restrict__ depth, const int32_t* __restrict__ rect,
     const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_prefix,
-    uint32_t dmin, int low_bits, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    uint32_t dmin, int low_bits, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+    uint32_t* __restrict__ ranges, int n_range_words) {
     __shared__ uint32_t wtot[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
+    // tiles without instances keep the empty range [0,0): cleared here, ahead of
+    // tile_ranges_kernel on the same stream, instead of by a separate fill command
+    for (int k = i; k < n_range_words; k += gridDim.x * 256) ranges[k] = 0u;
     const uint32_t cnt = i < N ? tiles_touched[i] : 0u;
     const uint32_t inc = wave_scan_incl(cnt);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -265,8 +269,10 @@ extern "C" int vings_surfel_bin(int N, int H, int W, int64_t D, uint32_t depth_b
     hipStream_t s = (hipStream_t)stream;
     const int gx = (W + 15) / 16, gy = (H + 15) / 16;
     const int T = gx * gy;
-    VINGS_CHECK_HIP(hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)T, s));
-    if (D == 0 || N == 0) return VINGS_OK;
+    if (D == 0 || N == 0) {
+        VINGS_CHECK_HIP(hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)T, s));
+        return VINGS_OK;
+    }
     VINGS_REQUIRE(depth && rect && tiles_touched && block_prefix && keys_sorted && vals_sorted &&
                       workspace,
                   "null pointer");
@@ -292,7 +298,8 @@ extern "C" int vings_surfel_bin(int N, int H, int W, int64_t D, uint32_t depth_b
     int vcur = (passes % 2 == 0) ? 0 : 1;   // values: end in vbuf[0]
 
     emit_keys_kernel<<<cdiv(N, 256), 256, 0, s>>>(N, gx, depth, rect, tiles_touched, block_prefix,
-                                                  dmin, low_bits, kbuf[cur], vbuf[vcur]);
+                                                  dmin, low_bits, kbuf[cur], vbuf[vcur], ranges,
+                                                  2 * T);
     VINGS_LAUNCH_CHECK();
 
     const int ntiles = cdiv(D, kSortTile);
