@@ -180,8 +180,10 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": measured_traffic(args.splats, W, H), "avg_kernel_ms": round(avg_ms, 4),
                 "algorithmic_bytes": int(alg),
-                "note": "this kernel is bound by vector-ALU issue (SQ_INSTS_VALU x 4 cycles / "
-                        "1024 SIMDs ~ its duration), not by HBM"}
+                "note": "bound by vector-instruction issue, not by HBM: about 1.0e9 wave "
+                        "instructions per launch on 1024 SIMDs at the 2.6 (plain) to 12 (lane "
+                        "swap) cycles each costs on gfx950 (profiles/r1/valu_rate.txt, "
+                        "profiles/r1/blend_sq_counters.txt)"}
     stage_ms = {k: round(v["ms"] / max(v["count"], 1), 4) for k, v in prof_all.items()}
     if roof is not None:
         stage_ms["blend_bwd"] = roof["avg_kernel_ms"]     # the timed region's own figure
