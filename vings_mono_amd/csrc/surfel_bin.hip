@@ -134,7 +134,10 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(
     int ntiles, const uint32_t* __restrict__ thist, const uint32_t* __restrict__ totals) {
     __shared__ uint32_t wcount[4][kRadix];  // per-wave digit counts, then prefixes
     __shared__ uint32_t gbase[kRadix];
+    __shared__ uint32_t tile_off[kRadix];
     __shared__ uint32_t wsum4[4];
+    __shared__ uint64_t lkey[kSortTile];
+    __shared__ uint32_t lval[kSortTile];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int k = threadIdx.x; k < 4 * kRadix; k += kSortThreads) (&wcount[0][0])[k] = 0;
     // first output slot of digit d in this tile = keys with a smaller digit anywhere
@@ -176,7 +179,8 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    // exclusive prefix over the 4 waves for each digit
+    // per digit: exclusive prefix over the 4 waves; then the digit's first slot inside the tile
+    // (exclusive prefix of the tile's digit counts over the 256 digits, one per lane)
     {
         const int d = threadIdx.x;
         uint32_t run = 0;
@@ -186,16 +190,39 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(
             wcount[k][d] = run;
             run += c;
         }
+        const uint32_t inc2 = wave_scan_incl(run);
+        if (lane == 63) wsum4[w] = inc2;
+        __syncthreads();
+        uint32_t off = inc2 - run;
+        for (int k = 0; k < w; ++k) off += wsum4[k];
+        tile_off[d] = off;
+        gbase[d] -= off;   // output slot of tile position p with digit d = gbase[d] + p (mod 2^32)
     }
     __syncthreads();
+    // Sort the tile in LDS, then write it out in order: consecutive lanes then store to
+    // consecutive addresses inside each digit's run (a wave's store touches the few runs it
+    // spans instead of up to 64 scattered lines).
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         const int64_t i = wbase + r * 64 + lane;
         if (i < D) {
             const uint32_t d = digit_of(key[r], shift);
-            const uint32_t dst = gbase[d] + wcount[w][d] + rank[r];
-            keys_out[dst] = key[r];
-            vals_out[dst] = val[r];
+            const uint32_t p = tile_off[d] + wcount[w][d] + rank[r];
+            lkey[p] = key[r];
+            lval[p] = val[r];
+        }
+    }
+    __syncthreads();
+    const int64_t tile_base = (int64_t)blockIdx.x * kSortTile;
+    const uint32_t n_valid = (uint32_t)min((int64_t)kSortTile, D - tile_base);
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const uint32_t p = r * kSortThreads + threadIdx.x;
+        if (p < n_valid) {
+            const uint64_t k = lkey[p];
+            const uint32_t dst = gbase[digit_of(k, shift)] + p;
+            keys_out[dst] = k;
+            vals_out[dst] = lval[p];
         }
     }
 }
