@@ -35,6 +35,9 @@ __global__ __launch_bounds__(256) void emit_keys_kernel(
     uint32_t dmin, int low_bits, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
     uint32_t* __restrict__ ranges, int n_range_words) {
     __shared__ uint32_t wtot[4];
+    __shared__ uint32_t start[257];     // first output slot of each splat, relative to the block
+    __shared__ int4 srect[256];
+    __shared__ uint32_t sdepth[256];
     const int i = blockIdx.x * 256 + threadIdx.x;
     // tiles without instances keep the empty range [0,0): cleared here, ahead of
     // tile_ranges_kernel on the same stream, instead of by a separate fill command
@@ -44,20 +47,34 @@ __global__ __launch_bounds__(256) void emit_keys_kernel(
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 63) wtot[w] = inc;
     __syncthreads();
-    uint32_t off = block_prefix[blockIdx.x] + inc - cnt;
+    uint32_t off = inc - cnt;
     for (int k = 0; k < w; ++k) off += wtot[k];
-    if (cnt == 0) return;
-    const int4 r = reinterpret_cast<const int4*>(rect)[i];
-    // sort key: tile above the depth bits rebased to the smallest depth of the view, so the
-    // sort only runs over bits that can differ (same order as tile << 32 | depth bits)
-    const uint64_t dlow = (uint64_t)(__float_as_uint(depth[i]) - dmin);
-    for (int y = r.y; y < r.w; ++y)
-        for (int x = r.x; x < r.z; ++x) {
-            const uint64_t key = ((uint64_t)(uint32_t)(y * gx + x) << low_bits) | dlow;
-            keys[off] = key;
-            vals[off] = (uint32_t)i;
-            ++off;
-        }
+    start[threadIdx.x] = off;
+    if (threadIdx.x == 255) start[256] = off + cnt;
+    if (cnt) {
+        srect[threadIdx.x] = reinterpret_cast<const int4*>(rect)[i];
+        // sort key: tile above the depth bits rebased to the smallest depth of the view, so
+        // the sort only runs over bits that can differ (same order as tile << 32 | depth bits)
+        sdepth[threadIdx.x] = __float_as_uint(depth[i]) - dmin;
+    }
+    __syncthreads();
+    // The block's instances form one contiguous output range; lanes take consecutive slots
+    // (coalesced stores) and look up the owning splat by bisection over the 256 starts.
+    const uint32_t total = start[256];
+    const uint32_t out0 = block_prefix[blockIdx.x];
+    for (uint32_t q = threadIdx.x; q < total; q += 256) {
+        int lo = 0;                       // largest j with start[j] <= q (splats with cnt = 0
+#pragma unroll                            // share their start with the next one and lose)
+        for (int step = 128; step > 0; step >>= 1)
+            if (start[lo + step] <= q) lo += step;
+        const int4 r = srect[lo];
+        const uint32_t idx = q - start[lo];
+        const uint32_t wd = (uint32_t)(r.z - r.x);
+        const uint32_t row = idx / wd;
+        const uint32_t tile = (uint32_t)(r.y + (int)row) * gx + (uint32_t)r.x + (idx - row * wd);
+        keys[out0 + q] = ((uint64_t)tile << low_bits) | (uint64_t)sdepth[lo];
+        vals[out0 + q] = (uint32_t)(blockIdx.x * 256 + lo);
+    }
 }
 
 // ---------------------------------------------------------------------------
