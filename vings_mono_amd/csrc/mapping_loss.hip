@@ -465,20 +465,33 @@ __global__ __launch_bounds__(256) void geom_loss_kernel(int H, int W, GeomArgs g
 }
 
 // out[0..7] = total, rgb, normal, alpha, depth, dist loss terms (unweighted), n_valid, n_sky
-__global__ __launch_bounds__(256) void loss_final_kernel(
+__global__ __launch_bounds__(1024) void loss_final_kernel(
     const LossSums* __restrict__ sums, const double* __restrict__ ssim_parts, int n_ssim,
     const double* __restrict__ geom_parts, int n_geom, float w_rgb, float w_normal, float w_alpha,
     float w_depth, float w_dist, float* __restrict__ out) {
-    __shared__ double red[4];
+    // one workgroup of 1024 lanes: the kernel is a latency chain of strided loads, so the
+    // wider the group the shorter the chain
+    __shared__ double red[kSsimParts + kGeomParts][16];
     double acc[kSsimParts + kGeomParts] = {0, 0, 0, 0, 0, 0};
-    for (int i = threadIdx.x; i < n_ssim; i += 256)
+    for (int i = threadIdx.x; i < n_ssim; i += 1024)
         for (int k = 0; k < kSsimParts; ++k) acc[k] += ssim_parts[(size_t)i * kSsimParts + k];
-    for (int i = threadIdx.x; i < n_geom; i += 256)
+    for (int i = threadIdx.x; i < n_geom; i += 1024)
         for (int k = 0; k < kGeomParts; ++k)
             acc[kSsimParts + k] += geom_parts[(size_t)i * kGeomParts + k];
-    double tot[kSsimParts + kGeomParts];
-    for (int k = 0; k < kSsimParts + kGeomParts; ++k) tot[k] = block_sum(acc[k], red);
+    for (int k = 0; k < kSsimParts + kGeomParts; ++k) {
+        double v = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
     if (threadIdx.x != 0) return;
+    double tot[kSsimParts + kGeomParts];
+    for (int k = 0; k < kSsimParts + kGeomParts; ++k) {
+        double v = 0.0;
+        for (int w = 0; w < 16; ++w) v += red[k][w];
+        tot[k] = v;
+    }
     const double nv = (double)max(sums->n_valid, 1u), ns = (double)max(sums->n_sky, 1u);
     const double ssim = tot[0] / (3.0 * nv), l1 = tot[1] / (3.0 * nv);
     const double rgb = 0.8 * l1 + 0.2 * (1.0 - ssim);
@@ -558,7 +571,7 @@ extern "C" int vings_mapping_loss(int H, int W, const float* rgb, const float* a
     geom_loss_kernel<<<ggrid, 256, 0, s>>>(H, W, ga, allmap, gt_rgb, gt_depth, gt_depth_cov, sums,
                                            geom_parts, dL_dallmap);
     VINGS_LAUNCH_CHECK();
-    loss_final_kernel<<<1, 256, 0, s>>>(sums, ssim_parts, n_ssim, geom_parts, n_geom, w_rgb,
+    loss_final_kernel<<<1, 1024, 0, s>>>(sums, ssim_parts, n_ssim, geom_parts, n_geom, w_rgb,
                                         w_normal, w_alpha, w_depth, w_dist, loss_out);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
