@@ -10,15 +10,19 @@
 // A render wave then walks only the set bits of its own four ballots with
 // scalar bit scans, so splats that cannot reach the block cost nothing, and
 // reads each surviving record as an LDS broadcast (every lane the same
-// address: no bank conflicts).  Both kernels are bound by
-// vector-ALU issue (a wave64 instruction occupies a 16-lane SIMD for 4 cycles),
-// so the design rule is "fewest VALU instructions per (wave, splat) pair".
+// address: no bank conflicts).  Both kernels are bound by vector-instruction
+// issue (on gfx950, with two or more waves per SIMD: a plain VALU instruction
+// 2.6 cycles, one with an SGPR operand or a DPP modifier 4, v_rcp / v_exp 8,
+// v_permlane32_swap 10-12), so the design rule is "cheapest instruction stream
+// per (wave, splat) pair"; this file is built without SLP vectorisation, whose
+// v_pk_*_f32 pairs and register shuffles cost more than the scalar code.
 //
 // Backward walks the same bits back to front.  Per splat the 20 partial
 // gradients of the contributing pixels are summed over the wave with a
-// transposing permlane-swap tree, the four waves meet in an LDS accumulator for
-// the batch, and each batch is flushed with one global float atomic per
-// (splat, component).
+// transposing tree (cross-half exchange through the LDS crossbar, row pairs
+// with v_permlane16_swap, DPP inside a row), the four waves meet in an LDS
+// accumulator for the batch, and each batch is flushed with one global float
+// atomic per (splat, component).
 //
 // Serves GaussianRasterizer.forward / backward as called at
 // /root/reference/scripts/gaussian/gaussian_base.py:193-203,382 and consumed
@@ -34,9 +38,9 @@ constexpr float kAlphaMax = 0.99f;
 constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kTMin = 0.0001f;
 constexpr int kBatch = 256;
-// backward batch: 192 records keep the kernel at 31.6 KB of LDS, i.e. five workgroups per
-// CU (160 KB) instead of three with 256; its launch bound asks for 5 waves per SIMD (96
-// VGPRs: the staging code spills a little, the blend loop does not)
+// backward batch: 160 records keep the kernel at 26.4 KB of LDS, i.e. six workgroups per CU
+// (160 KB) instead of three with 256; its launch bound asks for 6 waves per SIMD (80 VGPRs:
+// the staging code spills a little, the blend loop does not)
 constexpr int kBatchBwd = 160;
 constexpr int kRec4 = VINGS_GEOM_STRIDE / 4;  // float4 per record
 constexpr int kGrad = VINGS_GRAD_STRIDE;      // gradient components per splat
