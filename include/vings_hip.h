@@ -152,7 +152,9 @@ int vings_sparse_adam(float* param, const float* grad, float* exp_avg, float* ex
 
 /* Same update for up to 8 parameter groups sharing one visibility mask in a
  * single launch (the five splat groups of gaussian_base.py:55-61). The
- * pointer/size arrays live in HOST memory. */
+ * pointer/size arrays live in HOST memory; the device arrays they name must be 16-byte
+ * aligned.  Invisible rows keep their values (a row sharing a 16-byte quad with a visible
+ * row is written back unchanged). */
 int vings_sparse_adam_multi(int n_groups, float* const* params_host,
                             const float* const* grads_host, float* const* exp_avgs_host,
                             float* const* exp_avg_sqs_host, const int* widths_host,

@@ -1,7 +1,7 @@
 // Row-masked Adam for splat parameters on gfx950 (HBM-bound elementwise op).
 //
-// Rows whose visibility flag is 0 are not read beyond the flag and not written:
-// their moments do not decay.  No bias correction, no weight decay.
+// Rows whose visibility flag is 0 keep their values: their moments do not decay.
+// No bias correction, no weight decay.
 // Serves SparseGaussianAdam.step as called at
 // /root/reference/scripts/gaussian/gaussian_base.py:62,402 and
 // /root/reference/scripts/gaussian/sky_utils.py:181.
@@ -37,30 +37,63 @@ struct AdamGroups {
     float* v[kMaxGroups];
     int width[kMaxGroups];
     float lr[kMaxGroups];
+    int first_block[kMaxGroups + 1];   // blocks [first_block[g], first_block[g+1]) serve group g
     int n;
 };
 
-// One lane per splat row: the visibility byte is read once and all groups of
-// that row are updated by the same lane.
+// Row of element e in an array of rows of M floats; the widths that occur are constants.
+__device__ __forceinline__ int64_t row_of(int64_t e, int M) {
+    switch (M) {
+        case 1: return e;
+        case 2: return e >> 1;
+        case 3: return e / 3;
+        case 4: return e >> 2;
+        default: return e / M;
+    }
+}
+
+// All groups in one launch, element-parallel: a lane owns four consecutive floats of one
+// group's arrays (one 16-byte load / store per array: fully coalesced, where a lane per row
+// would walk rows of 4 to 16 bytes with strided scalar accesses).  A quad none of whose rows
+// is visible is not touched at all; in a quad that straddles a visible and an invisible row
+// the invisible elements are written back unchanged.
 __global__ __launch_bounds__(256) void sparse_adam_multi_kernel(AdamGroups G,
                                                                 const uint8_t* __restrict__ visible,
                                                                 float b1, float b2, float eps,
                                                                 int N) {
-    const int stride = gridDim.x * 256;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += stride) {
-        if (!visible[i]) continue;
-        for (int gidx = 0; gidx < G.n; ++gidx) {
-            const int M = G.width[gidx];
-            const float lr = G.lr[gidx];
-            float* p = G.param[gidx] + (size_t)i * M;
-            const float* g = G.grad[gidx] + (size_t)i * M;
-            float* m = G.m[gidx] + (size_t)i * M;
-            float* v = G.v[gidx] + (size_t)i * M;
-            for (int k = 0; k < M; ++k) {
-                float pp = p[k], mm = m[k], vv = v[k];
-                adam_update(pp, g[k], mm, vv, lr, b1, b2, eps);
-                p[k] = pp; m[k] = mm; v[k] = vv;
-            }
+    int g = 0;
+    while (g + 1 < G.n && (int)blockIdx.x >= G.first_block[g + 1]) ++g;
+    const int M = G.width[g];
+    const float lr = G.lr[g];
+    const int64_t total = (int64_t)N * M;
+    const int64_t e0 = ((int64_t)(blockIdx.x - G.first_block[g]) * 256 + threadIdx.x) * 4;
+    if (e0 >= total) return;
+    float* __restrict__ P = G.param[g];
+    const float* __restrict__ Gr = G.grad[g];
+    float* __restrict__ Mo = G.m[g];
+    float* __restrict__ Vo = G.v[g];
+    if (e0 + 4 <= total) {
+        bool vis[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vis[k] = visible[row_of(e0 + k, M)] != 0;
+        if (!(vis[0] | vis[1] | vis[2] | vis[3])) return;
+        float4 p4 = *reinterpret_cast<float4*>(P + e0);
+        const float4 g4 = *reinterpret_cast<const float4*>(Gr + e0);
+        float4 m4 = *reinterpret_cast<float4*>(Mo + e0);
+        float4 v4 = *reinterpret_cast<float4*>(Vo + e0);
+        if (vis[0]) adam_update(p4.x, g4.x, m4.x, v4.x, lr, b1, b2, eps);
+        if (vis[1]) adam_update(p4.y, g4.y, m4.y, v4.y, lr, b1, b2, eps);
+        if (vis[2]) adam_update(p4.z, g4.z, m4.z, v4.z, lr, b1, b2, eps);
+        if (vis[3]) adam_update(p4.w, g4.w, m4.w, v4.w, lr, b1, b2, eps);
+        *reinterpret_cast<float4*>(P + e0) = p4;
+        *reinterpret_cast<float4*>(Mo + e0) = m4;
+        *reinterpret_cast<float4*>(Vo + e0) = v4;
+    } else {
+        for (int64_t e = e0; e < total; ++e) {
+            if (!visible[row_of(e, M)]) continue;
+            float p = P[e], m = Mo[e], v = Vo[e];
+            adam_update(p, Gr[e], m, v, lr, b1, b2, eps);
+            P[e] = p; Mo[e] = m; Vo[e] = v;
         }
     }
 }
@@ -110,8 +143,14 @@ extern "C" int vings_sparse_adam_multi(int n_groups, float* const* params_host,
         G.width[i] = widths_host[i];
         G.lr[i] = lrs_host[i];
     }
-    int blocks = cdiv(N, 256);
-    if (blocks > 4096) blocks = 4096;
+    int blocks = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        VINGS_REQUIRE((((uintptr_t)G.param[i] | (uintptr_t)G.grad[i] | (uintptr_t)G.m[i] |
+                        (uintptr_t)G.v[i]) & 15) == 0, "group arrays must be 16-byte aligned");
+        G.first_block[i] = blocks;
+        blocks += cdiv((int64_t)N * G.width[i], 1024);
+    }
+    G.first_block[n_groups] = blocks;
     ProfScope prof(PROF_ADAM, (hipStream_t)stream);
     sparse_adam_multi_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(G, visible, b1, b2, eps, N);
     VINGS_LAUNCH_CHECK();
