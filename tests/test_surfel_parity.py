@@ -242,15 +242,26 @@ def test_autograd_module_api():
     assert torch.equal(rgb2, rgb.detach())
 
 
-def test_sparse_adam_parity(oracle32):
+@pytest.mark.parametrize("N,offset", [(5000, 0), (5003, 0), (1, 0), (4097, 1)])
+def test_sparse_adam_parity(oracle32, N, offset):
+    """offset = 1: parameters are views one float into a larger buffer (not 16-byte aligned),
+    which takes the one-launch-per-group path; N*M not a multiple of 4 exercises the tail."""
     from vings_mono_amd.surfel import SparseGaussianAdam
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(2)
-    N = 5000
     widths = {"_xyz": 3, "_rgb": 3, "_opacity": 1, "_scaling": 2, "_rotation": 4}
     lrs = {"_xyz": 1.6e-4, "_rgb": 2.5e-3, "_opacity": 5e-2, "_scaling": 5e-3, "_rotation": 1e-3}
-    params = {k: torch.nn.Parameter(torch.from_numpy(rng.normal(size=(N, m)).astype(np.float32)).to(dev))
-              for k, m in widths.items()}
+
+    def make(k, m):
+        host = torch.from_numpy(rng.normal(size=(N, m)).astype(np.float32))
+        if offset == 0:
+            return torch.nn.Parameter(host.to(dev))
+        buf = torch.zeros(N * m + offset, device=dev)
+        view = buf[offset:].view(N, m)
+        view.copy_(host)
+        return torch.nn.Parameter(view)
+
+    params = {k: make(k, m) for k, m in widths.items()}
     opt = SparseGaussianAdam([{"params": [params[k]], "lr": lrs[k], "name": k} for k in widths],
                              lr=0.0, eps=1e-15)
     ref_p = {k: v.detach().cpu().numpy().copy() for k, v in params.items()}

@@ -294,6 +294,13 @@ class SparseGaussianAdam(torch.optim.Adam):
             for c0 in range(0, len(items), 8):
                 chunk = items[c0:c0 + 8]
                 n = len(chunk)
+                if any(ptr(t) % 16 for c in chunk for t in c[:4]):
+                    # the fused launch wants 16-byte aligned arrays (views into a larger
+                    # buffer may not be): one launch per group instead
+                    for p_, g_, m_, v_, width, lr in chunk:
+                        check(L.vings_sparse_adam(ptr(p_), ptr(g_), ptr(m_), ptr(v_), ptr(vis), lr,
+                                                  b1, b2, eps, N, width, stream), "vings_sparse_adam")
+                    continue
                 PP = (ctypes.c_void_p * n)(*[ptr(c[0]) for c in chunk])
                 GG = (ctypes.c_void_p * n)(*[ptr(c[1]) for c in chunk])
                 MM = (ctypes.c_void_p * n)(*[ptr(c[2]) for c in chunk])
