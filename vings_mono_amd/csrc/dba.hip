@@ -443,9 +443,15 @@ __global__ __launch_bounds__(256) void dba_linearize_kernel(
 // B[l>>4][l&15]; result reg r of lane l is C[(l>>4) + 4r][l&15].
 // ---------------------------------------------------------------------------
 using f64x4 = __attribute__((ext_vector_type(4))) double;
-constexpr int kSchurSlice = 512;
+// Pixels per workgroup: long slices amortise the scatter of a tile into S, short ones give a
+// small grid (the reference's own 43x77) enough workgroups to fill the chip.
+static int schur_slice(int HW, int M) {
+    int s = 512;
+    while (s > 64 && (int64_t)cdiv(HW, s) * M < 512) s >>= 1;
+    return s;
+}
 
-__global__ __launch_bounds__(256) void dba_schur_kernel(int HW, int P, DbaWs W) {
+__global__ __launch_bounds__(256) void dba_schur_kernel(int HW, int P, int slice, DbaWs W) {
     const int k = blockIdx.y;
     if (W.status[2]) return;
     const int n0 = W.ent_start[k], n1 = W.ent_start[k + 1];
@@ -455,8 +461,8 @@ __global__ __launch_bounds__(256) void dba_schur_kernel(int HW, int P, DbaWs W) 
     const int R16 = (nrows + 15) / 16;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int k0 = blockIdx.x * kSchurSlice;
-    const int k1 = min(HW, k0 + kSchurSlice);
+    const int k0 = blockIdx.x * slice;
+    const int k1 = min(HW, k0 + slice);
     const double* Qk = W.Q + (size_t)k * HW;
     const int n6 = 6 * P;
 
@@ -564,6 +570,69 @@ __global__ __launch_bounds__(1024) void dba_solve_kernel(int n, double lm, doubl
         for (int i = tid; i < j; i += 1024) y[i] -= A[j * n + i] * yj;
         __syncthreads();
     }
+}
+
+// The same solve for n <= 64 on ONE wave, lane i owning row i: the 1024-lane version spends
+// its time in five workgroup barriers per column, which for the 6P = 48..78 unknowns of a real
+// window is nearly all of it.  Same operation order, hence the same bits.  Rows are padded to
+// an odd number of doubles so that the lanes' row accesses spread over the LDS banks.
+__global__ __launch_bounds__(256) void dba_solve_wave_kernel(int n, double lm, double ep,
+                                                            int use_schur, DbaWs W) {
+    extern __shared__ double lds[];
+    __shared__ double col[64];
+    const int ld = n | 1;
+    double* A = lds;
+    double* y = lds + (size_t)n * ld;
+    const int i = threadIdx.x;
+    // four waves fetch the matrix (one wave alone would queue 36 dependent-latency rounds of
+    // global loads); from the barrier on only the first wave works, the others have ended
+    for (int idx = i; idx < n * n; idx += 256) {
+        const int r = idx / n, c = idx - r * n;
+        double a = W.H[idx];
+        if (r == c) a += ep + lm * a;
+        if (use_schur) a -= W.S[idx];
+        A[r * ld + c] = a;
+    }
+    if (i < n) y[i] = W.v[i] - (use_schur ? W.u[i] : 0.0);
+    __syncthreads();
+    if (i >= 64) return;
+    bool fail = false;
+    for (int j = 0; j < n; ++j) {
+        const double djj = A[j * ld + j];
+        if (!(djj > 0.0)) { fail = true; break; }      // uniform over the wave
+        const double inv = 1.0 / sqrt(djj);
+        double lij = 0.0;
+        if (i >= j && i < n) { lij = A[i * ld + j] * inv; A[i * ld + j] = lij; col[i] = lij; }
+        __syncthreads();
+        // the column sits in an array of its own: the compiler can then see that the row
+        // updates do not feed the column reads and overlap the LDS round trips
+        if (i > j && i < n) {
+            double* __restrict__ row = A + i * ld;
+#pragma unroll 8
+            for (int b = j + 1; b <= i; ++b) row[b] -= lij * col[b];
+        }
+        __syncthreads();
+    }
+    if (fail) {  // chol.py:9-17: a failed factorisation yields a zero update
+        if (i < n) W.dx[i] = 0.0;
+        if (i == 0) W.status[1] = 1;
+        return;
+    }
+    for (int j = 0; j < n; ++j) {
+        if (i == 0) y[j] /= A[j * ld + j];
+        __syncthreads();
+        const double yj = y[j];
+        if (i > j && i < n) y[i] -= A[i * ld + j] * yj;
+        __syncthreads();
+    }
+    for (int j = n - 1; j >= 0; --j) {
+        if (i == 0) y[j] /= A[j * ld + j];
+        __syncthreads();
+        const double yj = y[j];
+        if (i < j) y[i] -= A[j * ld + i] * yj;
+        __syncthreads();
+    }
+    if (i < n) W.dx[i] = y[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -687,8 +756,9 @@ static int stage_schur(const DbaDims& d, const DbaWs& W, hipStream_t s) {
     VINGS_CHECK_HIP(hipMemsetAsync(W.S, 0, sizeof(double) * n * n, s));
     VINGS_CHECK_HIP(hipMemsetAsync(W.u, 0, sizeof(double) * n, s));
     if (d.M > 0 && P > 0) {
-        dim3 grid(cdiv(HW, kSchurSlice), d.M);
-        dba_schur_kernel<<<grid, 256, 0, s>>>(HW, P, W);
+        const int slice = schur_slice(HW, d.M);
+        dim3 grid(cdiv(HW, slice), d.M);
+        dba_schur_kernel<<<grid, 256, 0, s>>>(HW, P, slice, W);
         VINGS_LAUNCH_CHECK();
     }
     return VINGS_OK;
@@ -699,6 +769,12 @@ static int stage_solve(const DbaDims& d, float lm, float ep, int motion_only, co
     const int n = 6 * (d.t1 - d.t0);
     if (n == 0) return VINGS_OK;
     ProfScope prof(PROF_DBA_SOLVE, s);
+    if (n <= 64) {
+        const size_t bytes = sizeof(double) * ((size_t)n * (n | 1) + n);
+        dba_solve_wave_kernel<<<1, 256, bytes, s>>>(n, (double)lm, (double)ep, motion_only ? 0 : 1, W);
+        VINGS_LAUNCH_CHECK();
+        return VINGS_OK;
+    }
     const size_t lds = n <= 128 ? sizeof(double) * (size_t)n * n : 0;
     if (lds > 48 * 1024)
         VINGS_CHECK_HIP(hipFuncSetAttribute((const void*)dba_solve_kernel,
