@@ -443,15 +443,23 @@ __global__ __launch_bounds__(256) void dba_linearize_kernel(
 // B[l>>4][l&15]; result reg r of lane l is C[(l>>4) + 4r][l&15].
 // ---------------------------------------------------------------------------
 using f64x4 = __attribute__((ext_vector_type(4))) double;
-// Pixels per workgroup: long slices amortise the scatter of a tile into S, short ones give a
-// small grid (the reference's own 43x77) enough workgroups to fill the chip.
-static int schur_slice(int HW, int M) {
-    int s = 512;
-    while (s > 64 && (int64_t)cdiv(HW, s) * M < 512) s >>= 1;
+constexpr int kSchurSlice = 64;
+// 64 rows + the Q row, 65 doubles each = 33 KB of LDS: four workgroups per CU
+constexpr size_t kSchurLds = (size_t)65 * (kSchurSlice + 1) * sizeof(double);
+// Pixels per workgroup: long spans amortise the scatter of the tiles into S, short ones give
+// a small grid (the reference's own 43x77) enough workgroups to fill the chip.
+static int schur_span(int HW, int M) {
+    int s = 2048;
+    while (s > kSchurSlice && (int64_t)cdiv(HW, s) * M < 512) s >>= 1;
     return s;
 }
 
-__global__ __launch_bounds__(256) void dba_schur_kernel(int HW, int P, int slice, DbaWs W) {
+// A workgroup covers `span` pixels of depth variable k in chunks of `slice` (a power of two)
+// staged through LDS, keeps its tiles' accumulators in registers over the chunks and
+// scatters them once: the float64 atomics into S were half of the kernel's time when every
+// 128-pixel slice scattered its own tiles.
+__global__ __launch_bounds__(256) void dba_schur_kernel(int HW, int P, int slice, int span,
+                                                        DbaWs W) {
     const int k = blockIdx.y;
     if (W.status[2]) return;
     const int n0 = W.ent_start[k], n1 = W.ent_start[k + 1];
@@ -461,8 +469,8 @@ __global__ __launch_bounds__(256) void dba_schur_kernel(int HW, int P, int slice
     const int R16 = (nrows + 15) / 16;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int k0 = blockIdx.x * slice;
-    const int k1 = min(HW, k0 + slice);
+    const int k0 = blockIdx.x * span;
+    const int k1 = min(HW, k0 + span);
     const double* Qk = W.Q + (size_t)k * HW;
     const int n6 = 6 * P;
 
@@ -472,27 +480,7 @@ __global__ __launch_bounds__(256) void dba_schur_kernel(int HW, int P, int slice
         const int ent = rho / 6, c = rho - ent * 6;
         return W.E + ((size_t)W.ent_row[n0 + ent] * 6 + c) * HW;
     };
-
-    for (int t = wv; t < R16 * R16; t += 4) {
-        const int rb = t / R16, cb = t - rb * R16;
-        if (cb < rb) continue;  // symmetric: upper tiles only
-        const double* pa = row_ptr(rb * 16 + r);
-        const double* pb = row_ptr(cb * 16 + r);
-        f64x4 acc = {0., 0., 0., 0.};
-        for (int kk = k0; kk < k1; kk += 16) {
-            const int px = kk + 4 * g;  // this lane's 4 consecutive pixels
-            double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (px + s < k1) {
-                    if (pa) a[s] = pa[px + s] * Qk[px + s];
-                    if (pb) b[s] = pb[px + s];
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
-        }
+    auto scatter = [&](int rb, int cb, const f64x4& acc) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int ra = rb * 16 + g + 4 * reg, rc = cb * 16 + r;
@@ -510,6 +498,81 @@ __global__ __launch_bounds__(256) void dba_schur_kernel(int HW, int P, int slice
                 if (rb != cb) atomicAdd(&W.S[(size_t)ibx * n6 + ia], val);
             }
         }
+    };
+
+    extern __shared__ double ys[];
+    const int ld = slice + 1;          // odd: the 16 rows of a panel spread over the banks
+    const bool staged = R16 <= 4 && (size_t)(R16 * 16 + 1) * ld * sizeof(double) <= kSchurLds;
+    if (staged) {
+        // Every row's chunk is staged in LDS once: each of the R16 (R16+1)/2 tiles re-reads
+        // two 16-row panels, which from global memory is 3-4x the traffic of E.
+        double* qs = ys + (size_t)R16 * 16 * ld;
+        __shared__ const double* rows[64];
+        // row addresses first (each costs a dependent table lookup), then copies with
+        // nothing but independent loads in their loop
+        if ((int)threadIdx.x < R16 * 16) rows[threadIdx.x] = row_ptr(threadIdx.x);
+        const int sh = __builtin_ctz(slice);
+        f64x4 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = f64x4{0., 0., 0., 0.};
+        for (int c0 = k0; c0 < k1; c0 += slice) {
+            __syncthreads();           // rows[] written / previous chunk consumed
+#pragma unroll 4
+            for (int idx = threadIdx.x; idx < R16 * 16 * slice; idx += 256) {
+                const int rho = idx >> sh, px = idx & (slice - 1);
+                const double* rp = rows[rho];
+                ys[rho * ld + px] = (rp && c0 + px < k1) ? rp[c0 + px] : 0.0;
+            }
+            for (int px = threadIdx.x; px < slice; px += 256) qs[px] = c0 + px < k1 ? Qk[c0 + px] : 0.0;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = wv + 4 * q;
+                if (t >= R16 * R16) break;
+                const int rb = t / R16, cb = t - rb * R16;
+                if (cb < rb) continue;  // symmetric: upper tiles only
+                const double* pa = ys + (rb * 16 + r) * ld;
+                const double* pb = ys + (cb * 16 + r) * ld;
+                for (int kk = 0; kk < slice; kk += 16) {
+                    const int px = kk + 4 * g;  // this lane's 4 consecutive pixels
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[px + s] * qs[px + s],
+                                                                      pb[px + s], acc[q], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = wv + 4 * q;
+            if (t >= R16 * R16) break;
+            const int rb = t / R16, cb = t - rb * R16;
+            if (cb >= rb) scatter(rb, cb, acc[q]);
+        }
+        return;
+    }
+    // more than 64 rows (over ten edges leaving one frame): panels straight from global memory
+    for (int t = wv; t < R16 * R16; t += 4) {
+        const int rb = t / R16, cb = t - rb * R16;
+        if (cb < rb) continue;
+        f64x4 acc = {0., 0., 0., 0.};
+        const double* pa = row_ptr(rb * 16 + r);
+        const double* pb = row_ptr(cb * 16 + r);
+        for (int kk = k0; kk < k1; kk += 16) {
+            const int px = kk + 4 * g;
+            double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (px + s < k1) {
+                    if (pa) a[s] = pa[px + s] * Qk[px + s];
+                    if (pb) b[s] = pb[px + s];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
+        }
+        scatter(rb, cb, acc);
     }
 }
 
@@ -756,9 +819,16 @@ static int stage_schur(const DbaDims& d, const DbaWs& W, hipStream_t s) {
     VINGS_CHECK_HIP(hipMemsetAsync(W.S, 0, sizeof(double) * n * n, s));
     VINGS_CHECK_HIP(hipMemsetAsync(W.u, 0, sizeof(double) * n, s));
     if (d.M > 0 && P > 0) {
-        const int slice = schur_slice(HW, d.M);
-        dim3 grid(cdiv(HW, slice), d.M);
-        dba_schur_kernel<<<grid, 256, 0, s>>>(HW, P, slice, W);
+        const int span = schur_span(HW, d.M);
+        dim3 grid(cdiv(HW, span), d.M);
+        static bool lds_set = false;
+        if (!lds_set) {
+            VINGS_CHECK_HIP(hipFuncSetAttribute((const void*)dba_schur_kernel,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)kSchurLds));
+            lds_set = true;
+        }
+        dba_schur_kernel<<<grid, 256, kSchurLds, s>>>(HW, P, kSchurSlice, span, W);
         VINGS_LAUNCH_CHECK();
     }
     return VINGS_OK;
