@@ -216,6 +216,10 @@ __global__ __launch_bounds__(256) void dba_index_kernel(const int64_t* __restric
     __shared__ int flag[kMaxFrames];
     __shared__ int pos[kMaxFrames];
     __shared__ int bad;
+    // endpoints of the first kLdsEdges edges: the list building below is a serial double loop
+    // of one lane, which out of global memory costs a cache round trip per step
+    constexpr int kLdsEdges = 2048;
+    __shared__ short sip[kLdsEdges], sjp[kLdsEdges];
     const int tid = threadIdx.x;
     if (tid == 0) bad = 0;
     for (int f = tid; f < B; f += 256) flag[f] = (f >= t0 && f < t1) ? 1 : 0;
@@ -224,6 +228,7 @@ __global__ __launch_bounds__(256) void dba_index_kernel(const int64_t* __restric
         const long a = ii[e], b = jj[e];
         if (a < 0 || a >= B || b < 0 || b >= B) { bad = 1; W.ip[e] = 0; W.jp[e] = 0; continue; }
         W.ip[e] = (int)a; W.jp[e] = (int)b;
+        if (e < kLdsEdges) { sip[e] = (short)a; sjp[e] = (short)b; }
         flag[a] = 1;
     }
     __syncthreads();
@@ -255,9 +260,9 @@ __global__ __launch_bounds__(256) void dba_index_kernel(const int64_t* __restric
             const int f = W.kx[k];
             if (f >= t0 && f < t1) { W.ent_row[cn] = f - t0; W.ent_pose[cn] = f - t0; ++cn; }
             for (int e = 0; e < E; ++e) {
-                if (W.ip[e] != f) continue;
+                if ((e < kLdsEdges ? (int)sip[e] : W.ip[e]) != f) continue;
                 W.kedges[ce++] = e;
-                const int j = W.jp[e];
+                const int j = e < kLdsEdges ? (int)sjp[e] : W.jp[e];
                 if (j >= t0 && j < t1) { W.ent_row[cn] = (t1 - t0) + e; W.ent_pose[cn] = j - t0; ++cn; }
             }
         }
@@ -791,17 +796,22 @@ static int check_dims(const DbaDims& d) {
     return VINGS_OK;
 }
 
+// build_index = false: the tables of dba_index_kernel (functions of ii, jj, t0, t1 only) are
+// already in the workspace from an earlier iteration of the same call
 static int stage_linearize(const float* poses, const float* disps, const float* intr,
                            const float* disps_sens, const float* target, const float* weight,
                            const float* eta, const int64_t* ii, const int64_t* jj,
-                           const DbaDims& d, int motion_only, const DbaWs& W, hipStream_t s) {
+                           const DbaDims& d, int motion_only, const DbaWs& W, hipStream_t s,
+                           bool build_index = true) {
     const int P = d.t1 - d.t0, HW = d.ht * d.wd;
     const size_t n = 6 * (size_t)P;
     ProfScope prof(PROF_DBA_JAC, s);
     VINGS_CHECK_HIP(hipMemsetAsync(W.H, 0, sizeof(double) * n * n, s));
     VINGS_CHECK_HIP(hipMemsetAsync(W.v, 0, sizeof(double) * n, s));
-    dba_index_kernel<<<1, 256, 0, s>>>(ii, jj, d.B, d.E, d.M, d.t0, d.t1, W);
-    VINGS_LAUNCH_CHECK();
+    if (build_index) {
+        dba_index_kernel<<<1, 256, 0, s>>>(ii, jj, d.B, d.E, d.M, d.t0, d.t1, W);
+        VINGS_LAUNCH_CHECK();
+    }
     if (d.M > 0 && d.E > 0) {
         dim3 grid(cdiv(HW, 256), d.M);
         dba_linearize_kernel<<<grid, 256, 0, s>>>(poses, disps, intr, disps_sens, target, weight,
@@ -961,7 +971,7 @@ extern "C" int vings_dba_ba(float* poses, float* disps, const float* intr,
     if (E == 0 || t1 == t0) return VINGS_OK;
     for (int it = 0; it < itrs; ++it) {
         int rc = stage_linearize(poses, disps, intr, disps_sens, target, weight, eta, ii, jj, dims,
-                                 motion_only, W, s);
+                                 motion_only, W, s, it == 0);
         if (rc != VINGS_OK) return rc;
         if (!motion_only) { rc = stage_schur(dims, W, s); if (rc != VINGS_OK) return rc; }
         rc = stage_solve(dims, lm, ep, motion_only, W, s);
