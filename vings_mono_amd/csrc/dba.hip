@@ -644,13 +644,18 @@ __global__ __launch_bounds__(1024) void dba_solve_kernel(int n, double lm, doubl
 // its time in five workgroup barriers per column, which for the 6P = 48..78 unknowns of a real
 // window is nearly all of it.  Same operation order, hence the same bits.  Rows are padded to
 // an odd number of doubles so that the lanes' row accesses spread over the LDS banks.
+__device__ __forceinline__ double lane_bcast(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(256) void dba_solve_wave_kernel(int n, double lm, double ep,
                                                             int use_schur, DbaWs W) {
     extern __shared__ double lds[];
     __shared__ double col[64];
     const int ld = n | 1;
     double* A = lds;
-    double* y = lds + (size_t)n * ld;
     const int i = threadIdx.x;
     // four waves fetch the matrix (one wave alone would queue 36 dependent-latency rounds of
     // global loads); from the barrier on only the first wave works, the others have ended
@@ -661,14 +666,15 @@ __global__ __launch_bounds__(256) void dba_solve_wave_kernel(int n, double lm, d
         if (use_schur) a -= W.S[idx];
         A[r * ld + c] = a;
     }
-    if (i < n) y[i] = W.v[i] - (use_schur ? W.u[i] : 0.0);
     __syncthreads();
     if (i >= 64) return;
     bool fail = false;
+    double rd = 0.0;                                   // 1 / L[i][i], kept by lane i
     for (int j = 0; j < n; ++j) {
         const double djj = A[j * ld + j];
         if (!(djj > 0.0)) { fail = true; break; }      // uniform over the wave
         const double inv = 1.0 / sqrt(djj);
+        if (i == j) rd = inv;
         double lij = 0.0;
         if (i >= j && i < n) { lij = A[i * ld + j] * inv; A[i * ld + j] = lij; col[i] = lij; }
         __syncthreads();
@@ -686,21 +692,23 @@ __global__ __launch_bounds__(256) void dba_solve_wave_kernel(int n, double lm, d
         if (i == 0) W.status[1] = 1;
         return;
     }
-    for (int j = 0; j < n; ++j) {
-        if (i == 0) y[j] /= A[j * ld + j];
-        __syncthreads();
-        const double yj = y[j];
-        if (i > j && i < n) y[i] -= A[i * ld + j] * yj;
-        __syncthreads();
+    // Substitutions with the right-hand side in registers (lane i holds y[i]); the pivot
+    // element travels by v_readlane and is multiplied by the reciprocal pivot, so a step is
+    // a few dependent instructions instead of two LDS round trips, a division and two barriers.
+    const bool live = i < n;
+    double yi = live ? W.v[i] - (use_schur ? W.u[i] : 0.0) : 0.0;
+    const double* rowi = A + (live ? i : 0) * ld;
+    for (int j = 0; j < n; ++j) {                      // L y = b
+        const double yj = lane_bcast(yi, j) * lane_bcast(rd, j);
+        if (i == j) yi = yj;
+        if (live && i > j) yi -= rowi[j] * yj;
     }
-    for (int j = n - 1; j >= 0; --j) {
-        if (i == 0) y[j] /= A[j * ld + j];
-        __syncthreads();
-        const double yj = y[j];
-        if (i < j) y[i] -= A[j * ld + i] * yj;
-        __syncthreads();
+    for (int j = n - 1; j >= 0; --j) {                 // L^T x = y
+        const double yj = lane_bcast(yi, j) * lane_bcast(rd, j);
+        if (i == j) yi = yj;
+        if (i < j) yi -= A[j * ld + i] * yj;
     }
-    if (i < n) W.dx[i] = y[i];
+    if (live) W.dx[i] = yi;
 }
 
 // ---------------------------------------------------------------------------
@@ -850,7 +858,7 @@ static int stage_solve(const DbaDims& d, float lm, float ep, int motion_only, co
     if (n == 0) return VINGS_OK;
     ProfScope prof(PROF_DBA_SOLVE, s);
     if (n <= 64) {
-        const size_t bytes = sizeof(double) * ((size_t)n * (n | 1) + n);
+        const size_t bytes = sizeof(double) * (size_t)n * (n | 1);
         dba_solve_wave_kernel<<<1, 256, bytes, s>>>(n, (double)lm, (double)ep, motion_only ? 0 : 1, W);
         VINGS_LAUNCH_CHECK();
         return VINGS_OK;
