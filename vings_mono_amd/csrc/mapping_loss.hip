@@ -312,7 +312,9 @@ __device__ __forceinline__ float depth_of(float a0, float alpha) {
     return (d == d && fabsf(d) != INFINITY) ? d : 0.f;   // nan / +-inf -> 0
 }
 
-constexpr int kGT = 16;  // geometry tile
+// geometry tile: 32 pixels wide so that a row of the tile is one full 128-byte line of every
+// plane (with 16 x 16 tiles every access touched half-used lines)
+constexpr int kGW = 32, kGH = 8;
 
 // Depth / normal / alpha / distortion terms -> dL/dallmap (all nine channels written).
 __global__ __launch_bounds__(256) void geom_loss_kernel(int H, int W, GeomArgs ga,
@@ -323,14 +325,14 @@ __global__ __launch_bounds__(256) void geom_loss_kernel(int H, int W, GeomArgs g
                                                         const LossSums* __restrict__ sums,
                                                         double* __restrict__ partials,
                                                         float* __restrict__ dL_dallmap) {
-    __shared__ float dep[kGT + 4][kGT + 5];
-    __shared__ float G[kGT + 2][kGT + 2][7];   // dL/d(dx), dL/d(dy) of the pixel's normal (+pad)
+    __shared__ float dep[kGH + 4][kGW + 5];
+    __shared__ float G[kGH + 2][kGW + 2][7];   // dL/d(dx), dL/d(dy) of the pixel's normal (+pad)
     __shared__ double red[4];
     const size_t HW = (size_t)H * W;
-    const int tx0 = blockIdx.x * kGT, ty0 = blockIdx.y * kGT;
+    const int tx0 = blockIdx.x * kGW, ty0 = blockIdx.y * kGH;
     const float nv = (float)max(sums->n_valid, 1u), ns = (float)max(sums->n_sky, 1u);
-    for (int idx = threadIdx.x; idx < (kGT + 4) * (kGT + 4); idx += 256) {
-        const int r = idx / (kGT + 4), cc = idx - r * (kGT + 4);
+    for (int idx = threadIdx.x; idx < (kGH + 4) * (kGW + 4); idx += 256) {
+        const int r = idx / (kGW + 4), cc = idx - r * (kGW + 4);
         const int gy = ty0 + r - 2, gx = tx0 + cc - 2;
         float d = 0.f;
         if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
@@ -348,12 +350,12 @@ __global__ __launch_bounds__(256) void geom_loss_kernel(int H, int W, GeomArgs g
         x = (v - ga.cv) * inv_fv * d; y = (u - ga.cu) * inv_fu * d; z = d;
     };
     double normal_acc = 0.0;
-    for (int idx = threadIdx.x; idx < (kGT + 2) * (kGT + 2); idx += 256) {
-        const int r = idx / (kGT + 2), cc = idx - r * (kGT + 2);  // G coordinates
+    for (int idx = threadIdx.x; idx < (kGH + 2) * (kGW + 2); idx += 256) {
+        const int r = idx / (kGW + 2), cc = idx - r * (kGW + 2);  // G coordinates
         const int gy = ty0 + r - 1, gx = tx0 + cc - 1;
         float gdx[3] = {0, 0, 0}, gdy[3] = {0, 0, 0};
         const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const bool owned = r >= 1 && r <= kGT && cc >= 1 && cc <= kGT;
+        const bool owned = r >= 1 && r <= kGH && cc >= 1 && cc <= kGW;
         if (in) {
             const size_t p = (size_t)gy * W + gx;
             const bool valid = !is_sky(gt_rgb, HW, p) && gt_depth[p] > 0.0f;
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(256) void geom_loss_kernel(int H, int W, GeomArgs g
     }
     __syncthreads();
     // owned pixel of this lane
-    const int lr = threadIdx.x >> 4, lc = threadIdx.x & 15;
+    const int lr = threadIdx.x >> 5, lc = threadIdx.x & 31;
     const int gy = ty0 + lr, gx = tx0 + lc;
     double alpha_acc = 0.0, depth_acc = 0.0, dist_acc = 0.0;
     if (gy < H && gx < W) {
@@ -511,7 +513,7 @@ using namespace vings;
 // workspace = [LossSums | ssim partials | geom partials | 9 derivative maps]
 static size_t partial_bytes(int H, int W) {
     const size_t n = (size_t)cdiv(W, kST) * cdiv(H, kST) * kSsimParts +
-                     (size_t)cdiv(W, kGT) * cdiv(H, kGT) * kGeomParts;
+                     (size_t)cdiv(W, kGW) * cdiv(H, kGH) * kGeomParts;
     return (n * sizeof(double) + 255) / 256 * 256;
 }
 
@@ -534,7 +536,7 @@ extern "C" int vings_mapping_loss(int H, int W, const float* rgb, const float* a
     VINGS_REQUIRE(fu != 0.f && fv != 0.f, "focal lengths");
     hipStream_t s = (hipStream_t)stream;
     LossSums* sums = reinterpret_cast<LossSums*>(workspace);
-    const int n_ssim = cdiv(W, kST) * cdiv(H, kST), n_geom = cdiv(W, kGT) * cdiv(H, kGT);
+    const int n_ssim = cdiv(W, kST) * cdiv(H, kST), n_geom = cdiv(W, kGW) * cdiv(H, kGH);
     double* ssim_parts = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + kSumsBytes);
     double* geom_parts = ssim_parts + (size_t)n_ssim * kSsimParts;
     float* maps = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kSumsBytes +
@@ -567,7 +569,7 @@ extern "C" int vings_mapping_loss(int H, int W, const float* rgb, const float* a
     ssim_bwd_kernel<<<sgrid, 256, 0, s>>>(H, W, gw, w_rgb, rgb, gt_rgb, gt_depth, maps, sums,
                                           dL_drgb);
     VINGS_LAUNCH_CHECK();
-    const dim3 ggrid(cdiv(W, kGT), cdiv(H, kGT));
+    const dim3 ggrid(cdiv(W, kGW), cdiv(H, kGH));
     geom_loss_kernel<<<ggrid, 256, 0, s>>>(H, W, ga, allmap, gt_rgb, gt_depth, gt_depth_cov, sums,
                                            geom_parts, dL_dallmap);
     VINGS_LAUNCH_CHECK();
