@@ -57,14 +57,21 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// Pixel classes of the ground truth, one byte per pixel: the three later kernels read this
+// instead of re-deriving it from four float planes each.
+constexpr uint8_t kPixValid = 1, kPixSky = 2;
+
 __global__ __launch_bounds__(256) void loss_count_kernel(size_t HW, const float* __restrict__ gt_rgb,
                                                          const float* __restrict__ gt_depth,
-                                                         LossSums* __restrict__ sums) {
+                                                         LossSums* __restrict__ sums,
+                                                         uint8_t* __restrict__ cls) {
     unsigned nv = 0, ns = 0;
     for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < HW; p += (size_t)gridDim.x * 256) {
         const bool sky = is_sky(gt_rgb, HW, p);
+        const bool valid = (!sky) && gt_depth[p] > 0.0f;
         ns += sky;
-        nv += (!sky) && gt_depth[p] > 0.0f;
+        nv += valid;
+        cls[p] = sky ? kPixSky : (valid ? kPixValid : 0);
     }
     __shared__ unsigned cnt[2][4];
     nv = wave_sum_u32(nv);
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(256) void loss_count_kernel(size_t HW, const float*
 __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, Gauss gw,
                                                        const float* __restrict__ rgb,
                                                        const float* __restrict__ gt_rgb,
-                                                       const float* __restrict__ gt_depth,
+                                                       const uint8_t* __restrict__ cls,
                                                        float* __restrict__ maps,
                                                        double* __restrict__ partials) {
     __shared__ float sx[kSIn][kSIn + 1], sy[kSIn][kSIn + 1];
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, Gauss gw,
         vld[i] = false;
         if (gy < H && gx < W) {
             const size_t p = (size_t)gy * W + gx;
-            vld[i] = !is_sky(gt_rgb, HW, p) && gt_depth[p] > 0.0f;
+            vld[i] = cls[p] == kPixValid;
         }
     }
     for (int ch = 0; ch < 3; ++ch) {
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, Gauss gw,
 __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, Gauss gw, float w_rgb,
                                                        const float* __restrict__ rgb,
                                                        const float* __restrict__ gt_rgb,
-                                                       const float* __restrict__ gt_depth,
+                                                       const uint8_t* __restrict__ cls,
                                                        const float* __restrict__ maps,
                                                        const LossSums* __restrict__ sums,
                                                        float* __restrict__ dL_drgb) {
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, Gauss gw, f
         vld[i] = false;
         if (gy < H && gx < W) {
             const size_t p = (size_t)gy * W + gx;
-            vld[i] = !is_sky(gt_rgb, HW, p) && gt_depth[p] > 0.0f;
+            vld[i] = cls[p] == kPixValid;
         }
     }
     for (int ch = 0; ch < 3; ++ch) {
@@ -319,7 +326,7 @@ constexpr int kGW = 32, kGH = 8;
 // Depth / normal / alpha / distortion terms -> dL/dallmap (all nine channels written).
 __global__ __launch_bounds__(256) void geom_loss_kernel(int H, int W, GeomArgs ga,
                                                         const float* __restrict__ allmap,
-                                                        const float* __restrict__ gt_rgb,
+                                                        const uint8_t* __restrict__ cls,
                                                         const float* __restrict__ gt_depth,
                                                         const float* __restrict__ gt_cov,
                                                         const LossSums* __restrict__ sums,
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(256) void geom_loss_kernel(int H, int W, GeomArgs g
         const bool owned = r >= 1 && r <= kGH && cc >= 1 && cc <= kGW;
         if (in) {
             const size_t p = (size_t)gy * W + gx;
-            const bool valid = !is_sky(gt_rgb, HW, p) && gt_depth[p] > 0.0f;
+            const bool valid = cls[p] == kPixValid;
             const bool interior = gy >= 1 && gy <= H - 2 && gx >= 1 && gx <= W - 2;
             float nh[3] = {0, 0, 0};  // surface normal (camera frame); zero on the border
             float dxv[3], dyv[3], inv_len = 0.f;
@@ -422,8 +429,8 @@ __global__ __launch_bounds__(256) void geom_loss_kernel(int H, int W, GeomArgs g
     if (gy < H && gx < W) {
         const size_t p = (size_t)gy * W + gx;
         const int r = lr + 1, cc = lc + 1;  // G coordinates
-        const bool sky = is_sky(gt_rgb, HW, p);
-        const bool valid = !sky && gt_depth[p] > 0.0f;
+        const bool sky = cls[p] == kPixSky;
+        const bool valid = cls[p] == kPixValid;
         // P(p) enters dx of the left neighbour (+), of the right neighbour (-),
         // dy of the lower neighbour (+) and of the upper neighbour (-)
         float dP[3];
@@ -510,7 +517,7 @@ constexpr size_t kSumsBytes = 256;  // LossSums padded so the maps stay 256-byte
 
 using namespace vings;
 
-// workspace = [LossSums | ssim partials | geom partials | 9 derivative maps]
+// workspace = [LossSums | ssim partials | geom partials | 9 derivative maps | pixel classes]
 static size_t partial_bytes(int H, int W) {
     const size_t n = (size_t)cdiv(W, kST) * cdiv(H, kST) * kSsimParts +
                      (size_t)cdiv(W, kGW) * cdiv(H, kGH) * kGeomParts;
@@ -518,7 +525,7 @@ static size_t partial_bytes(int H, int W) {
 }
 
 extern "C" size_t vings_mapping_loss_workspace_bytes(int H, int W) {
-    return kSumsBytes + partial_bytes(H, W) + sizeof(float) * 9 * (size_t)H * (size_t)W;
+    return kSumsBytes + partial_bytes(H, W) + (sizeof(float) * 9 + 1) * (size_t)H * (size_t)W;
 }
 
 extern "C" int vings_mapping_loss(int H, int W, const float* rgb, const float* allmap,
@@ -542,6 +549,7 @@ extern "C" int vings_mapping_loss(int H, int W, const float* rgb, const float* a
     float* maps = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kSumsBytes +
                                            partial_bytes(H, W));
     const size_t HW = (size_t)H * W;
+    uint8_t* cls = reinterpret_cast<uint8_t*>(maps + 9 * HW);
     // the Gaussian window of loss_utils.py:26-28 (sigma 1.5, normalised), in float like there
     Gauss gw;
     {
@@ -561,16 +569,16 @@ extern "C" int vings_mapping_loss(int H, int W, const float* rgb, const float* a
 
     ProfScope prof(PROF_LOSS, s);
     VINGS_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(LossSums), s));
-    loss_count_kernel<<<min(cdiv((int64_t)HW, 1024), 1024), 256, 0, s>>>(HW, gt_rgb, gt_depth, sums);
+    loss_count_kernel<<<min(cdiv((int64_t)HW, 1024), 1024), 256, 0, s>>>(HW, gt_rgb, gt_depth, sums, cls);
     VINGS_LAUNCH_CHECK();
     const dim3 sgrid(cdiv(W, kST), cdiv(H, kST));
-    ssim_fwd_kernel<<<sgrid, 256, 0, s>>>(H, W, gw, rgb, gt_rgb, gt_depth, maps, ssim_parts);
+    ssim_fwd_kernel<<<sgrid, 256, 0, s>>>(H, W, gw, rgb, gt_rgb, cls, maps, ssim_parts);
     VINGS_LAUNCH_CHECK();
-    ssim_bwd_kernel<<<sgrid, 256, 0, s>>>(H, W, gw, w_rgb, rgb, gt_rgb, gt_depth, maps, sums,
+    ssim_bwd_kernel<<<sgrid, 256, 0, s>>>(H, W, gw, w_rgb, rgb, gt_rgb, cls, maps, sums,
                                           dL_drgb);
     VINGS_LAUNCH_CHECK();
     const dim3 ggrid(cdiv(W, kGW), cdiv(H, kGH));
-    geom_loss_kernel<<<ggrid, 256, 0, s>>>(H, W, ga, allmap, gt_rgb, gt_depth, gt_depth_cov, sums,
+    geom_loss_kernel<<<ggrid, 256, 0, s>>>(H, W, ga, allmap, cls, gt_depth, gt_depth_cov, sums,
                                            geom_parts, dL_dallmap);
     VINGS_LAUNCH_CHECK();
     loss_final_kernel<<<1, 1024, 0, s>>>(sums, ssim_parts, n_ssim, geom_parts, n_geom, w_rgb,
