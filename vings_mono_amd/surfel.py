@@ -108,7 +108,7 @@ def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys,
     nb = (N + 255) // 256
     st.geom = torch.empty((max(N, 1), GEOM_STRIDE), dtype=torch.float32, device=dev)
     st.depth = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
-    st.radii = torch.zeros(N, dtype=torch.int32, device=dev)
+    st.radii = torch.empty(N, dtype=torch.int32, device=dev)   # written for every splat
     st.rect = torch.empty((max(N, 1), 4), dtype=torch.int32, device=dev)
     st.tiles_touched = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
     st.block_prefix = torch.empty(3 * nb + 4, dtype=torch.int32, device=dev)
