@@ -178,3 +178,25 @@ def test_dropin_modules_expose_reference_names():
     core = d.BACore()
     for n in ("init", "hessian", "hessian_expand", "retract"):
         assert callable(getattr(core, n))
+
+
+@pytest.mark.gpu
+def test_profile_select_limits_the_timed_stages():
+    """Only the selected stage is bracketed by events; the others report nothing."""
+    import torch
+    from vings_mono_amd import harness, profiling, synth
+    dev = torch.device("cuda:0")
+    W, H = 160, 96
+    raw = synth.make_splats(2000, W, H, n_views=1, seed=3)
+    intr = synth.intrinsic_for(W, H)
+    w2c = torch.linalg.inv(synth.window_poses(1)[0]).to(dev)
+    params = {k: v.to(dev) for k, v in raw.items()}
+    profiling.select(["blend_fwd"])
+    profiling.enable(True)
+    with torch.no_grad():
+        harness.render(params, w2c, intr)
+    torch.cuda.synchronize()
+    got = profiling.read()
+    profiling.select(None)
+    profiling.enable(False)
+    assert set(got) == {"blend_fwd"} and got["blend_fwd"]["count"] == 1
