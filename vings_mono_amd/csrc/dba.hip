@@ -814,8 +814,9 @@ static int stage_linearize(const float* poses, const float* disps, const float* 
     const int P = d.t1 - d.t0, HW = d.ht * d.wd;
     const size_t n = 6 * (size_t)P;
     ProfScope prof(PROF_DBA_JAC, s);
-    VINGS_CHECK_HIP(hipMemsetAsync(W.H, 0, sizeof(double) * n * n, s));
-    VINGS_CHECK_HIP(hipMemsetAsync(W.v, 0, sizeof(double) * n, s));
+    // H, v, S and u lie next to each other in the workspace: one fill command clears the
+    // four accumulators of this iteration (the Schur stage always follows this one)
+    VINGS_CHECK_HIP(hipMemsetAsync(W.H, 0, (size_t)((char*)(W.u + n) - (char*)W.H), s));
     if (build_index) {
         dba_index_kernel<<<1, 256, 0, s>>>(ii, jj, d.B, d.E, d.M, d.t0, d.t1, W);
         VINGS_LAUNCH_CHECK();
@@ -832,10 +833,7 @@ static int stage_linearize(const float* poses, const float* disps, const float* 
 
 static int stage_schur(const DbaDims& d, const DbaWs& W, hipStream_t s) {
     const int P = d.t1 - d.t0, HW = d.ht * d.wd;
-    const size_t n = 6 * (size_t)P;
     ProfScope prof(PROF_DBA_SCHUR, s);
-    VINGS_CHECK_HIP(hipMemsetAsync(W.S, 0, sizeof(double) * n * n, s));
-    VINGS_CHECK_HIP(hipMemsetAsync(W.u, 0, sizeof(double) * n, s));
     if (d.M > 0 && P > 0) {
         const int span = schur_span(HW, d.M);
         dim3 grid(cdiv(HW, span), d.M);
