@@ -1,8 +1,9 @@
 """Times the stages either side of the mapping hot path on one MI355X and prints one JSON
 object: loop closure at the 5M-splat / 64-keyframe size (importance scoring, per-splat
 re-anchor, tracker refresh), keyframe arrival (3-NN scale initialisation, back-projection,
-pruning compaction) and the tracker -> mapper packaging kernels (upsampling, depth
-covariance, keyframe packaging).  Every figure is the median of `--reps` timed calls between
+pruning compaction), the tracker -> mapper packaging kernels (upsampling, depth
+covariance, keyframe packaging) and one dense bundle-adjustment call on the reference's
+own grid and on the 1080p/8 grid.  Every figure is the median of `--reps` timed calls between
 device events on the stream the library launches on; algorithmic bytes are given beside the
 time so the achieved bandwidth can be read off.
 
@@ -136,6 +137,12 @@ def main():
     ids = list(range(2, 2 + Kf))
     t = timed(lambda: TP.package_keyframes(images, up_d + 0.05, cov_up, ids, 40.0, 3.0), a.reps)
     res["package_keyframes"] = entry(t, Kf * H * W * (3 * 4 + 11 + 12 + 4 + 8))
+    # ---- dense bundle adjustment, one ba(itrs=2) call end to end -------------------------------
+    from vings_mono_amd import dba as dba_mod
+    for name, (gh, gw) in (("ba_itrs2_43x77", (43, 77)), ("ba_itrs2_135x240", (135, 240))):
+        prob = dba_mod.make_bench_problem(dev, gh, gw)
+        t = timed(prob.run, a.reps)
+        res[name] = entry(t, **prob.describe())
     print(json.dumps(res))
 
 
