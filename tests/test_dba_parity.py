@@ -248,3 +248,25 @@ def test_corr_index_parity(half):
         refb = O.corr_index_backward(vol.shape, coords, tg.float().cpu().numpy(), r)
         tolb = 2e-2 if half else 1e-5
         np.testing.assert_allclose(gv.float().cpu().numpy(), refb, rtol=tolb, atol=tolb)
+
+
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("r", [3, 2])
+def test_corr_index_forward_reference_grid(half, r):
+    """The lookup at the reference's own grid (43 x 77: a pixel count that is no multiple of the
+    64 pixels a wave takes) for radius 3 (cooperative kernel) and 2 (lane-per-pixel kernel);
+    float tolerance 1e-5, half 2e-3 (output rounding)."""
+    from vings_mono_amd import dba
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(16 + r)
+    E, h, w = 2, 43, 77
+    for lvl in (0, 2):
+        h2, w2 = h >> lvl, w >> lvl
+        vol = rng.normal(size=(E, h, w, h2, w2)).astype(np.float32)
+        coords = np.stack([rng.uniform(-5, w2 + 4, size=(E, h, w)),
+                           rng.uniform(-5, h2 + 4, size=(E, h, w))], 1).astype(np.float32)
+        tv = torch.from_numpy(vol).to(dev).to(torch.float16 if half else torch.float32)
+        got, = dba.corr_index_forward(tv, torch.from_numpy(coords).to(dev), r)
+        ref = O.corr_index_forward(tv.float().cpu().numpy(), coords, r)
+        tol = 2e-3 if half else 1e-5
+        np.testing.assert_allclose(got.float().cpu().numpy(), ref, rtol=tol, atol=tol)

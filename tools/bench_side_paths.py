@@ -143,6 +143,27 @@ def main():
         prob = dba_mod.make_bench_problem(dev, gh, gw)
         t = timed(prob.run, a.reps)
         res[name] = entry(t, **prob.describe())
+    # ---- the tracker's other two native calls, at the reference's own sizes -------------------
+    E_, h1, w1 = 48, 43, 77
+    coords = torch.stack(torch.meshgrid(torch.arange(w1, device=dev, dtype=torch.float32),
+                                        torch.arange(h1, device=dev, dtype=torch.float32),
+                                        indexing="xy"), 0)[None].repeat(E_, 1, 1, 1)
+    coords = (coords + torch.randn_like(coords) * 3).contiguous()
+    total = 0.0
+    nbytes = 0
+    for lvl in range(4):
+        h2, w2 = h1 >> lvl, w1 >> lvl
+        vol = torch.randn(E_, h1, w1, h2, w2, device=dev, dtype=torch.float16)
+        c = (coords / 2 ** lvl).contiguous()
+        total += timed(lambda: dba_mod.corr_index_forward(vol, c, 3), a.reps)
+        nbytes += E_ * h1 * w1 * 49 * 2 * 5     # 49 outputs, four taps each, float16
+        del vol
+    res["corr_index_forward_4_levels"] = entry(total, nbytes, edges=E_, grid=[h1, w1], radius=3)
+    prob = dba_mod.make_bench_problem(dev, h1, w1)
+    ii = torch.arange(0, 8, device=dev).repeat_interleave(8)
+    jj = torch.arange(0, 8, device=dev).repeat(8)
+    t = timed(lambda: dba_mod.frame_distance(prob.poses, prob.disps, prob.intr, ii, jj, 0.3), a.reps)
+    res["frame_distance_64_pairs"] = entry(t)
     print(json.dumps(res))
 
 

@@ -119,6 +119,70 @@ __global__ __launch_bounds__(256) void corr_index_fwd_kernel(
     }
 }
 
+// The same lookup for r = 3, with a wave instead of a lane per source pixel while it READS:
+// a lane that owns a pixel walks an 8 x 8 patch of its own h2 x w2 slice, so every load of the
+// kernel above touches 64 cache lines for 64 two- or four-byte values.  Here the wave takes 64
+// consecutive pixels one after the other, its 64 lanes fetch the 8 x 8 patch of that pixel in
+// one load (8 segments of a row each), form the 7 x 7 bilinear values from the lane's right
+// and lower neighbours and park them in LDS; at the end lane p writes the 49 values of pixel
+// p, consecutive lanes to consecutive addresses as before.
+template <typename T>
+__global__ __launch_bounds__(256) void corr_index_fwd_r3_kernel(
+    const T* __restrict__ volume, const float* __restrict__ coords, T* __restrict__ corr, int E,
+    int h1, int w1, int h2, int w2) {
+    constexpr int r = 3, rd = 7;
+    __shared__ T out_s[4][rd * rd][65];           // [wave][output][pixel], padded against conflicts
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int plane = h1 * w1;
+    const int groups = (plane + 63) / 64;
+    const int gid = blockIdx.x * 4 + wv;
+    if (gid >= E * groups) return;                // whole waves only; no workgroup barrier below
+    const int e = gid / groups, yx0 = (gid - e * groups) * 64;
+    const int yx = yx0 + lane;
+    const bool live = yx < plane;
+    const float cxv = live ? coords[((size_t)e * 2 + 0) * plane + yx] : 0.f;
+    const float cyv = live ? coords[((size_t)e * 2 + 1) * plane + yx] : 0.f;
+    const float fx0 = floorf(cxv), fy0 = floorf(cyv);
+    const float dx = cxv - fx0, dy = cyv - fy0;
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const int pi = lane >> 3, pj = lane & 7;      // this lane's element of a pixel's patch
+    const int npix = min(64, plane - yx0);
+    const size_t slice_sz = (size_t)h2 * w2;
+    const T* base = volume + ((size_t)e * plane + yx0) * slice_sz;
+    // eight pixels per round, so that eight patch loads are in flight together
+    for (int p0 = 0; p0 < npix; p0 += 8) {
+        float v[8], dxs[8], dys[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int p = p0 + q;                  // < 64: readlane stays inside the wave
+            const int x0p = __builtin_amdgcn_readlane(x0, p), y0p = __builtin_amdgcn_readlane(y0, p);
+            dxs[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dx), p));
+            dys[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dy), p));
+            const int yi = y0p - r + pi, xi = x0p - r + pj;
+            v[q] = (p < npix && yi >= 0 && yi < h2 && xi >= 0 && xi < w2)
+                       ? to_f(base[(size_t)p * slice_sz + (size_t)yi * w2 + xi]) : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float right = __shfl_down(v[q], 1, 64);
+            const float down = __shfl_down(v[q], 8, 64);
+            const float dright = __shfl_down(right, 8, 64);
+            const float dxp = dxs[q], dyp = dys[q];
+            const float o = (1.f - dxp) * (1.f - dyp) * v[q] + dxp * (1.f - dyp) * right +
+                            (1.f - dxp) * dyp * down + dxp * dyp * dright;
+            if (pi < rd && pj < rd && p0 + q < npix) from_f(out_s[wv][pi * rd + pj][p0 + q], o);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (live) {
+#pragma unroll 7
+        for (int k = 0; k < rd * rd; ++k)
+            corr[((size_t)e * rd * rd + k) * plane + yx] = out_s[wv][k][lane];
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void corr_index_bwd_kernel(
     const float* __restrict__ coords, const T* __restrict__ corr_grad, T* __restrict__ volume_grad,
@@ -177,6 +241,18 @@ extern "C" int vings_corr_index_forward(const void* volume, const float* coords,
     VINGS_REQUIRE(volume && coords && corr, "null pointer");
     const int64_t n = (int64_t)E * h1 * w1;
     ProfScope prof(PROF_AUX, (hipStream_t)stream);
+    if (r == 3) {
+        const int groups = cdiv((int64_t)h1 * w1, 64);
+        const int blocks = cdiv((int64_t)E * groups, 4);
+        if (half)
+            corr_index_fwd_r3_kernel<__half><<<blocks, 256, 0, (hipStream_t)stream>>>(
+                (const __half*)volume, coords, (__half*)corr, E, h1, w1, h2, w2);
+        else
+            corr_index_fwd_r3_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>(
+                (const float*)volume, coords, (float*)corr, E, h1, w1, h2, w2);
+        VINGS_LAUNCH_CHECK();
+        return VINGS_OK;
+    }
     if (half)
         corr_index_fwd_kernel<__half><<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(
             (const __half*)volume, coords, (__half*)corr, E, h1, w1, h2, w2, r);
