@@ -82,6 +82,21 @@ int vings_surfel_project(int N, int H, int W, float scale_modifier,
                          int64_t* num_instances_host, uint32_t* depth_bits_range_host,
                          void* stream);
 
+/* The same call in two halves, for callers that do not want the GPU to idle while the host
+ * learns D: launch returns at once; wait blocks until the projection launched last on the
+ * current GPU has finished (on an event behind it, not on the whole stream) and returns its
+ * D and depth-bit range.  Between the two the caller may enqueue more work on the stream,
+ * typically vings_surfel_bin_speculative and the blend sized from the previous view's count.
+ * One launch may be outstanding per GPU. */
+int vings_surfel_project_launch(int N, int H, int W, float scale_modifier,
+                                const float* means3D, const float* scales,
+                                const float* rotations, const float* opacities,
+                                const float* colors, const float* flow,
+                                const float* viewmatrix, const float* projmatrix,
+                                float* geom, float* depth, int32_t* radii, int32_t* rect,
+                                uint32_t* tiles_touched, uint32_t* block_prefix, void* stream);
+int vings_surfel_project_wait(int64_t* num_instances_host, uint32_t* depth_bits_range_host);
+
 /* Bytes of scratch vings_surfel_bin needs for D instances. */
 size_t vings_surfel_bin_workspace_bytes(int64_t D);
 
@@ -99,6 +114,21 @@ int vings_surfel_bin(int N, int H, int W, int64_t D, uint32_t depth_bits_min,
                      const uint32_t* tiles_touched, const uint32_t* block_prefix,
                      uint64_t* keys_sorted, uint32_t* vals_sorted, uint32_t* ranges,
                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* Stage 2 launched before the host knows D: buffers (keys_sorted, vals_sorted, workspace)
+ * hold D_capacity instances, low_bits_guess is the number of depth key bits assumed
+ * (vings_surfel_bin_low_bits of an earlier view's range), and the kernels read the true
+ * {depth_bits_min, depth_bits_max, D} from tail = block_prefix + 3*ceil(N/256) + 1 of the
+ * projection on the same stream.  Nothing is written beyond the capacity.  The result equals
+ * that of vings_surfel_bin iff D <= D_capacity and vings_surfel_bin_low_bits(true range) <=
+ * low_bits_guess and yields the same number of sort passes; the caller checks this after
+ * vings_surfel_project_wait and otherwise repeats the stage with vings_surfel_bin. */
+int vings_surfel_bin_low_bits(uint32_t depth_bits_min, uint32_t depth_bits_max);
+int vings_surfel_bin_speculative(int N, int H, int W, int64_t D_capacity, int low_bits_guess,
+                                 const uint32_t* tail, const float* depth, const int32_t* rect,
+                                 const uint32_t* tiles_touched, const uint32_t* block_prefix,
+                                 uint64_t* keys_sorted, uint32_t* vals_sorted, uint32_t* ranges,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Stage 3: front-to-back alpha blend, one workgroup per 16x16 tile.

@@ -16,6 +16,7 @@ import pytest
 import torch
 
 from scenes import oracle_forward, scene
+from vings_mono_amd import surfel, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -281,3 +282,47 @@ def test_sparse_adam_parity(oracle32, N, offset):
         np.testing.assert_array_equal(params[k].detach().cpu().numpy(), ref_p[k])
         np.testing.assert_array_equal(opt.state[params[k]]["exp_avg"].cpu().numpy(), ref_m[k])
         np.testing.assert_array_equal(opt.state[params[k]]["exp_avg_sq"].cpu().numpy(), ref_v[k])
+
+
+def _forward_state(raw, W, H, view=0, keep_keys=True):
+    dev = torch.device("cuda:0")
+    from vings_mono_amd import harness
+    intr = synth.intrinsic_for(W, H)
+    w2c = torch.linalg.inv(synth.window_poses(max(view + 1, 1))[view]).to(dev)
+    act = synth.activate({k: v.to(dev) for k, v in raw.items()})
+    return surfel.rasterize_forward(act["means3D"], act["colors"], act["opacities"].contiguous(),
+                                    act["scales"].contiguous(), act["rotations"].contiguous(),
+                                    harness.view_settings(w2c, intr), keep_keys=keep_keys)[0]
+
+
+def _same_state(a, b):
+    D = a.D
+    assert b.D == D
+    for name in ("ranges", "radii", "n_contrib", "color", "allmap", "final_T"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert torch.equal(a.keys[:D], b.keys[:D]) and torch.equal(a.vals[:D], b.vals[:D])
+
+
+def test_speculative_launch_equals_exact_launch():
+    """The forward pass launched before the host knows the instance count (sized from the
+    previous view) must give bit-identical results to the exact launch: same scene twice, then
+    a much larger scene (capacity guess too small) and a scene with a wider depth range (key
+    width guess too small), which must fall back to the exact launch."""
+    W, H = 320, 192
+    small = synth.make_splats(3000, W, H, n_views=2, seed=41, z_range=(4.0, 6.0))
+    big = synth.make_splats(40000, W, H, n_views=2, seed=42, z_range=(1.5, 60.0))
+    surfel.SPECULATE = False
+    try:
+        want_small = _forward_state(small, W, H)
+        want_small1 = _forward_state(small, W, H, view=1)
+        want_big = _forward_state(big, W, H)
+    finally:
+        surfel.SPECULATE = True
+    surfel._D_HINT.clear()
+    _same_state(want_small, _forward_state(small, W, H))        # no hint yet: exact path
+    assert surfel._D_HINT
+    _same_state(want_small, _forward_state(small, W, H))        # guess fits
+    _same_state(want_small1, _forward_state(small, W, H, view=1))
+    _same_state(want_big, _forward_state(big, W, H))            # count and key width too small
+    _same_state(want_big, _forward_state(big, W, H))            # guess fits again
+    _same_state(want_small, _forward_state(small, W, H))        # guess far too large: still exact

@@ -20,6 +20,11 @@ _SIGNATURES = {
     "vings_abi_version": (_c.c_int, []),
     "vings_surfel_project": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float] + [_P] * 14 +
                              [_c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32), _P]),
+    "vings_surfel_project_launch": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float] + [_P] * 15),
+    "vings_surfel_project_wait": (_c.c_int, [_c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
+    "vings_surfel_bin_low_bits": (_c.c_int, [_c.c_uint32, _c.c_uint32]),
+    "vings_surfel_bin_speculative": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_int] +
+                                     [_P] * 9 + [_c.c_size_t, _P]),
     "vings_surfel_bin_workspace_bytes": (_c.c_size_t, [_c.c_int64]),
     "vings_surfel_bin": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_uint32,
                                     _c.c_uint32] + [_P] * 8 + [_c.c_size_t, _P]),

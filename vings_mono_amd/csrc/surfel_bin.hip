@@ -33,7 +33,12 @@ __global__ __launch_bounds__(256) void emit_keys_kernel(
     int N, int gx, const float* __restrict__ depth, const int32_t* __restrict__ rect,
     const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_prefix,
     uint32_t dmin, int low_bits, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-    uint32_t* __restrict__ ranges, int n_range_words) {
+    uint32_t* __restrict__ ranges, int n_range_words, const uint32_t* __restrict__ tail,
+    uint32_t cap) {
+    // tail != NULL: the launch was sized from a guess; the true {smallest depth bits, largest,
+    // instance count} are read here from where the projection left them, and nothing is
+    // written beyond the `cap` entries the buffers hold
+    if (tail) dmin = tail[0];
     __shared__ uint32_t wtot[4];
     __shared__ uint32_t start[257];     // first output slot of each splat, relative to the block
     __shared__ int4 srect[256];
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(256) void emit_keys_kernel(
     // (coalesced stores) and look up the owning splat by bisection over the 256 starts.
     const uint32_t total = start[256];
     const uint32_t out0 = block_prefix[blockIdx.x];
-    for (uint32_t q = threadIdx.x; q < total; q += 256) {
+    for (uint32_t q = threadIdx.x; q < total && out0 + q < cap; q += 256) {
         int lo = 0;                       // largest j with start[j] <= q (splats with cnt = 0
 #pragma unroll                            // share their start with the next one and lose)
         for (int step = 128; step > 0; step >>= 1)
@@ -87,8 +92,9 @@ __device__ __forceinline__ uint32_t digit_of(uint64_t k, int shift) {
 // Per-tile digit histogram of one pass: thist[digit][tile].
 __global__ __launch_bounds__(kSortThreads) void sort_tile_hist_kernel(
     const uint64_t* __restrict__ keys, int64_t D, int shift, int ntiles,
-    uint32_t* __restrict__ thist) {
+    uint32_t* __restrict__ thist, const uint32_t* __restrict__ tail) {
     __shared__ uint32_t h[kRadix];
+    if (tail) D = min(D, (int64_t)tail[2]);
     h[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * kSortTile;
@@ -148,8 +154,10 @@ __global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t* __restrict__ t
 __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(
     const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t D, int shift,
-    int ntiles, const uint32_t* __restrict__ thist, const uint32_t* __restrict__ totals) {
+    int ntiles, const uint32_t* __restrict__ thist, const uint32_t* __restrict__ totals,
+    const uint32_t* __restrict__ tail) {
     __shared__ uint32_t wcount[4][kRadix];  // per-wave digit counts, then prefixes
+    if (tail) D = min(D, (int64_t)tail[2]);
     __shared__ uint32_t gbase[kRadix];
     __shared__ uint32_t tile_off[kRadix];
     __shared__ uint32_t wsum4[4];
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(
     }
     __syncthreads();
     const int64_t tile_base = (int64_t)blockIdx.x * kSortTile;
-    const uint32_t n_valid = (uint32_t)min((int64_t)kSortTile, D - tile_base);
+    const uint32_t n_valid = (uint32_t)max((int64_t)0, min((int64_t)kSortTile, D - tile_base));
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         const uint32_t p = r * kSortThreads + threadIdx.x;
@@ -249,13 +257,18 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint64_t* __restrict__ keys,
                                                           int64_t D, uint32_t dmin, int low_bits,
                                                           uint32_t* __restrict__ ranges,
-                                                          uint64_t* __restrict__ keys_out) {
+                                                          uint64_t* __restrict__ keys_out,
+                                                          const uint32_t* __restrict__ tail, int T) {
+    if (tail) { D = min(D, (int64_t)tail[2]); dmin = tail[0]; }
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= D) return;
     const uint64_t k = keys[i];
     const uint32_t t = (uint32_t)(k >> low_bits);
-    if (i == 0 || (uint32_t)(keys[i - 1] >> low_bits) != t) ranges[2 * t] = (uint32_t)i;
-    if (i == D - 1 || (uint32_t)(keys[i + 1] >> low_bits) != t) ranges[2 * t + 1] = (uint32_t)(i + 1);
+    // t >= T only when a guessed key width was too narrow (the caller then repeats the call)
+    if (t < (uint32_t)T) {
+        if (i == 0 || (uint32_t)(keys[i - 1] >> low_bits) != t) ranges[2 * t] = (uint32_t)i;
+        if (i == D - 1 || (uint32_t)(keys[i + 1] >> low_bits) != t) ranges[2 * t + 1] = (uint32_t)(i + 1);
+    }
     const uint32_t low = (uint32_t)(k & ((1ull << low_bits) - 1ull));
     keys_out[i] = ((uint64_t)t << 32) | (uint64_t)(low + dmin);
 }
@@ -301,12 +314,13 @@ using namespace vings;
 
 extern "C" size_t vings_surfel_bin_workspace_bytes(int64_t D) { return carve(nullptr, D).bytes; }
 
-extern "C" int vings_surfel_bin(int N, int H, int W, int64_t D, uint32_t depth_bits_min,
-                                uint32_t depth_bits_max, const float* depth,
-                                const int32_t* rect, const uint32_t* tiles_touched,
-                                const uint32_t* block_prefix, uint64_t* keys_sorted,
-                                uint32_t* vals_sorted, uint32_t* ranges, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+// tail == NULL: D, dmin and low_bits are the view's true values.  Otherwise D is the capacity
+// of the buffers and low_bits a guess, and the kernels take the true values from tail[0..2].
+static int bin_impl(int N, int H, int W, int64_t D, uint32_t dmin, int low_bits,
+                    const uint32_t* tail, const float* depth, const int32_t* rect,
+                    const uint32_t* tiles_touched, const uint32_t* block_prefix,
+                    uint64_t* keys_sorted, uint32_t* vals_sorted, uint32_t* ranges,
+                    void* workspace, size_t workspace_bytes, void* stream) {
     VINGS_REQUIRE(N >= 0 && H > 0 && W > 0 && D >= 0, "sizes");
     VINGS_REQUIRE(D < ((int64_t)1 << 32), "instance count must fit 32 bits");
     VINGS_REQUIRE(ranges != nullptr, "ranges");
@@ -326,11 +340,6 @@ extern "C" int vings_surfel_bin(int N, int H, int W, int64_t D, uint32_t depth_b
         set_error("bin workspace too small: %zu < %zu", workspace_bytes, b.bytes);
         return VINGS_ERR_CAPACITY;
     }
-    // depth bits are rebased to the view's smallest depth; an unknown range (min > max) keeps
-    // all 32 bits
-    const bool ranged = depth_bits_min <= depth_bits_max;
-    const uint32_t dmin = ranged ? depth_bits_min : 0u;
-    const int low_bits = ranged ? bits_for(depth_bits_max - depth_bits_min) : 32;
     const int passes = sort_passes(T, low_bits);
     VINGS_REQUIRE(passes <= kMaxPasses, "key too wide");
     ProfScope prof(PROF_BIN, s);
@@ -343,26 +352,61 @@ extern "C" int vings_surfel_bin(int N, int H, int W, int64_t D, uint32_t depth_b
 
     emit_keys_kernel<<<cdiv(N, 256), 256, 0, s>>>(N, gx, depth, rect, tiles_touched, block_prefix,
                                                   dmin, low_bits, kbuf[cur], vbuf[vcur], ranges,
-                                                  2 * T);
+                                                  2 * T, tail, (uint32_t)D);
     VINGS_LAUNCH_CHECK();
 
     const int ntiles = cdiv(D, kSortTile);
     for (int p = 0; p < passes; ++p) {
         const int shift = p * kRadixBits;
-        sort_tile_hist_kernel<<<ntiles, kSortThreads, 0, s>>>(kbuf[cur], D, shift, ntiles, b.thist);
+        sort_tile_hist_kernel<<<ntiles, kSortThreads, 0, s>>>(kbuf[cur], D, shift, ntiles, b.thist,
+                                                              tail);
         VINGS_LAUNCH_CHECK();
         sort_scan_kernel<<<kRadix, 256, 0, s>>>(b.thist, ntiles, b.ghist);
         VINGS_LAUNCH_CHECK();
         sort_scatter_kernel<<<ntiles, kSortThreads, 0, s>>>(kbuf[cur], vbuf[vcur], kbuf[cur ^ 1],
                                                             vbuf[vcur ^ 1], D, shift, ntiles,
-                                                            b.thist, b.ghist);
+                                                            b.thist, b.ghist, tail);
         VINGS_LAUNCH_CHECK();
         cur ^= 1;
         vcur ^= 1;
     }
     // cur == 1, vcur == 0 here by construction
     tile_ranges_kernel<<<cdiv(D, 256), 256, 0, s>>>(b.keys_alt, D, dmin, low_bits, ranges,
-                                                    keys_sorted);
+                                                    keys_sorted, tail, T);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
+}
+
+extern "C" int vings_surfel_bin(int N, int H, int W, int64_t D, uint32_t depth_bits_min,
+                                uint32_t depth_bits_max, const float* depth,
+                                const int32_t* rect, const uint32_t* tiles_touched,
+                                const uint32_t* block_prefix, uint64_t* keys_sorted,
+                                uint32_t* vals_sorted, uint32_t* ranges, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    // depth bits are rebased to the view's smallest depth; an unknown range (min > max) keeps
+    // all 32 bits
+    const bool ranged = depth_bits_min <= depth_bits_max;
+    return bin_impl(N, H, W, D, ranged ? depth_bits_min : 0u,
+                    ranged ? bits_for(depth_bits_max - depth_bits_min) : 32, nullptr, depth, rect,
+                    tiles_touched, block_prefix, keys_sorted, vals_sorted, ranges, workspace,
+                    workspace_bytes, stream);
+}
+
+extern "C" int vings_surfel_bin_low_bits(uint32_t depth_bits_min, uint32_t depth_bits_max) {
+    return depth_bits_min <= depth_bits_max ? bits_for(depth_bits_max - depth_bits_min) : 32;
+}
+
+extern "C" int vings_surfel_bin_speculative(int N, int H, int W, int64_t D_capacity,
+                                            int low_bits_guess, const uint32_t* tail,
+                                            const float* depth, const int32_t* rect,
+                                            const uint32_t* tiles_touched,
+                                            const uint32_t* block_prefix, uint64_t* keys_sorted,
+                                            uint32_t* vals_sorted, uint32_t* ranges,
+                                            void* workspace, size_t workspace_bytes,
+                                            void* stream) {
+    VINGS_REQUIRE(tail != nullptr && D_capacity > 0 && N > 0, "speculative binning needs a guess");
+    VINGS_REQUIRE(low_bits_guess >= 0 && low_bits_guess <= 32, "low_bits_guess");
+    return bin_impl(N, H, W, D_capacity, 0u, low_bits_guess, tail, depth, rect, tiles_touched,
+                    block_prefix, keys_sorted, vals_sorted, ranges, workspace, workspace_bytes,
+                    stream);
 }

@@ -352,11 +352,58 @@ namespace {
 constexpr int kMaxDevices = 64;
 std::mutex g_mail_mu[kMaxDevices];
 uint32_t* g_mail[kMaxDevices] = {};
+hipEvent_t g_mail_evt[kMaxDevices] = {};
 }  // namespace
 
 }  // namespace vings
 
 using namespace vings;
+
+// Launch half: projection + block scan, the three result words into the GPU's mailbox, and an
+// event behind them.
+static int project_launch(int N, int H, int W, float scale_modifier, const float* means3D,
+                          const float* scales, const float* rotations, const float* opacities,
+                          const float* colors, const float* flow, const float* viewmatrix,
+                          const float* projmatrix, float* geom, float* depth, int32_t* radii,
+                          int32_t* rect, uint32_t* tiles_touched, uint32_t* block_prefix,
+                          hipStream_t s, int* dev_out) {
+    VINGS_REQUIRE(N > 0 && H > 0 && W > 0, "sizes");
+    VINGS_REQUIRE(means3D && scales && rotations && opacities && colors && viewmatrix &&
+                      projmatrix && geom && depth && radii && rect && tiles_touched && block_prefix,
+                  "null pointer");
+    VINGS_REQUIRE((((uintptr_t)geom | (uintptr_t)rotations | (uintptr_t)rect) & 15) == 0,
+                  "geom/rotations/rect must be 16-byte aligned");
+    int dev = 0;
+    VINGS_CHECK_HIP(hipGetDevice(&dev));
+    VINGS_REQUIRE(dev >= 0 && dev < kMaxDevices, "device index");
+    if (!g_mail[dev]) VINGS_CHECK_HIP(hipHostMalloc((void**)&g_mail[dev], 64, hipHostMallocDefault));
+    if (!g_mail_evt[dev]) VINGS_CHECK_HIP(hipEventCreateWithFlags(&g_mail_evt[dev], hipEventDisableTiming));
+    const int nb = cdiv(N, 256);
+    {
+    ProfScope prof(PROF_PROJECT_FWD, s);
+    project_fwd_kernel<<<nb, 256, 0, s>>>(N, H, W, scale_modifier, means3D, scales, rotations,
+                                          opacities, colors, flow, viewmatrix, projmatrix, geom,
+                                          depth, radii, rect, tiles_touched, block_prefix,
+                                          block_prefix + nb + 1, block_prefix + 2 * nb + 1);
+    VINGS_LAUNCH_CHECK();
+    }
+    scan_blocks_kernel<<<1, 1024, 0, s>>>(block_prefix, nb, g_mail[dev]);
+    VINGS_LAUNCH_CHECK();
+    VINGS_CHECK_HIP(hipEventRecord(g_mail_evt[dev], s));
+    *dev_out = dev;
+    return VINGS_OK;
+}
+
+static int project_wait(int dev, int64_t* num_instances_host, uint32_t* depth_bits_range_host) {
+    VINGS_CHECK_HIP(hipEventSynchronize(g_mail_evt[dev]));
+    volatile uint32_t* tail = g_mail[dev];   // depth-bit min, max, instance total
+    *num_instances_host = (int64_t)tail[2];
+    if (depth_bits_range_host) {
+        depth_bits_range_host[0] = tail[2] > 0 ? tail[0] : 0u;
+        depth_bits_range_host[1] = tail[2] > 0 ? tail[1] : 0xFFFFFFFFu;
+    }
+    return VINGS_OK;
+}
 
 extern "C" int vings_surfel_project(int N, int H, int W, float scale_modifier,
                                     const float* means3D, const float* scales,
@@ -372,37 +419,40 @@ extern "C" int vings_surfel_project(int N, int H, int W, float scale_modifier,
     *num_instances_host = 0;
     if (depth_bits_range_host) { depth_bits_range_host[0] = 0u; depth_bits_range_host[1] = 0xFFFFFFFFu; }
     if (N == 0) return VINGS_OK;
-    VINGS_REQUIRE(means3D && scales && rotations && opacities && colors && viewmatrix &&
-                      projmatrix && geom && depth && radii && rect && tiles_touched && block_prefix,
-                  "null pointer");
-    VINGS_REQUIRE((((uintptr_t)geom | (uintptr_t)rotations | (uintptr_t)rect) & 15) == 0,
-                  "geom/rotations/rect must be 16-byte aligned");
-    hipStream_t s = (hipStream_t)stream;
-    const int nb = cdiv(N, 256);
-    {
-    ProfScope prof(PROF_PROJECT_FWD, s);
-    project_fwd_kernel<<<nb, 256, 0, s>>>(N, H, W, scale_modifier, means3D, scales, rotations,
-                                          opacities, colors, flow, viewmatrix, projmatrix, geom,
-                                          depth, radii, rect, tiles_touched, block_prefix,
-                                          block_prefix + nb + 1, block_prefix + 2 * nb + 1);
-    VINGS_LAUNCH_CHECK();
-    }
+    int cur = 0;
+    VINGS_CHECK_HIP(hipGetDevice(&cur));
+    VINGS_REQUIRE(cur >= 0 && cur < kMaxDevices, "device index");
+    // held until the words are read: calls on one GPU share its mailbox
+    std::lock_guard<std::mutex> lk(g_mail_mu[cur]);
+    int dev = 0;
+    const int rc = project_launch(N, H, W, scale_modifier, means3D, scales, rotations, opacities,
+                                  colors, flow, viewmatrix, projmatrix, geom, depth, radii, rect,
+                                  tiles_touched, block_prefix, (hipStream_t)stream, &dev);
+    if (rc != VINGS_OK) return rc;
+    return project_wait(dev, num_instances_host, depth_bits_range_host);
+}
+
+extern "C" int vings_surfel_project_launch(int N, int H, int W, float scale_modifier,
+                                           const float* means3D, const float* scales,
+                                           const float* rotations, const float* opacities,
+                                           const float* colors, const float* flow,
+                                           const float* viewmatrix, const float* projmatrix,
+                                           float* geom, float* depth, int32_t* radii,
+                                           int32_t* rect, uint32_t* tiles_touched,
+                                           uint32_t* block_prefix, void* stream) {
+    int dev = 0;
+    return project_launch(N, H, W, scale_modifier, means3D, scales, rotations, opacities, colors,
+                          flow, viewmatrix, projmatrix, geom, depth, radii, rect, tiles_touched,
+                          block_prefix, (hipStream_t)stream, &dev);
+}
+
+extern "C" int vings_surfel_project_wait(int64_t* num_instances_host,
+                                         uint32_t* depth_bits_range_host) {
+    VINGS_REQUIRE(num_instances_host != nullptr, "num_instances_host");
     int dev = 0;
     VINGS_CHECK_HIP(hipGetDevice(&dev));
-    VINGS_REQUIRE(dev >= 0 && dev < kMaxDevices, "device index");
-    // held until the words are read: calls on one GPU share its mailbox
-    std::lock_guard<std::mutex> lk(g_mail_mu[dev]);
-    if (!g_mail[dev]) VINGS_CHECK_HIP(hipHostMalloc((void**)&g_mail[dev], 64, hipHostMallocDefault));
-    volatile uint32_t* tail = g_mail[dev];   // depth-bit min, max, instance total
-    scan_blocks_kernel<<<1, 1024, 0, s>>>(block_prefix, nb, g_mail[dev]);
-    VINGS_LAUNCH_CHECK();
-    VINGS_CHECK_HIP(hipStreamSynchronize(s));
-    *num_instances_host = (int64_t)tail[2];
-    if (depth_bits_range_host && tail[2] > 0) {
-        depth_bits_range_host[0] = tail[0];
-        depth_bits_range_host[1] = tail[1];
-    }
-    return VINGS_OK;
+    VINGS_REQUIRE(dev >= 0 && dev < kMaxDevices && g_mail_evt[dev], "no projection was launched on this GPU");
+    return project_wait(dev, num_instances_host, depth_bits_range_host);
 }
 
 extern "C" int vings_surfel_project_backward(int N, int H, int W, float scale_modifier,

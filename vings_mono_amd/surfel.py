@@ -80,7 +80,8 @@ def view_importance(means3D, colors, opacities, scales, rotations, settings, out
     return out, st.radii
 
 
-_D_HINT = {}   # device index -> instance count of the latest forward pass
+SPECULATE = True   # launch sort + blend before the host has the instance count (see _forward)
+_D_HINT = {}       # (device index, H, W) -> (instance count, depth key bits) of the latest view
 
 
 def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys, blend):
@@ -114,54 +115,75 @@ def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys,
     st.block_prefix = torch.empty(3 * nb + 4, dtype=torch.int32, device=dev)
     T = ((W + TILE - 1) // TILE) * ((H + TILE - 1) // TILE)
     st.ranges = torch.empty((T, 2), dtype=torch.int32, device=dev)
-    # The projection call returns the instance count D to the host, and the GPU idles until the
-    # sort is launched.  Buffers sized from the previous view's count (plus 1/8) are therefore
-    # allocated BEFORE that call, so that nothing but the launch sits in the gap.
-    hint = _D_HINT.get(dev.index, 0)
-    pre = None
-    if hint > 0:
-        cap = hint + hint // 8 + 4096
-        cap_ws = int(L.vings_surfel_bin_workspace_bytes(cap))
-        pre = (cap, torch.empty(cap, dtype=torch.int64, device=dev),
-               torch.empty(cap, dtype=torch.int32, device=dev),
-               torch.empty(cap_ws + 256, dtype=torch.uint8, device=dev), cap_ws)
+    aux = (view, proj, bg, mask, flow)
+    project_args = (N, H, W, float(settings.scale_modifier), ptr(means3D), ptr(scales),
+                    ptr(rotations), ptr(opacities), ptr(colors), ptr(flow), ptr(view), ptr(proj),
+                    ptr(st.geom), ptr(st.depth), ptr(st.radii), ptr(st.rect),
+                    ptr(st.tiles_touched), ptr(st.block_prefix))
     d_host = ctypes.c_int64(0)
     d_range = (ctypes.c_uint32 * 2)(0, 0xFFFFFFFF)
-    check(L.vings_surfel_project(
-        N, H, W, float(settings.scale_modifier), ptr(means3D), ptr(scales), ptr(rotations),
-        ptr(opacities), ptr(colors), ptr(flow), ptr(view), ptr(proj), ptr(st.geom), ptr(st.depth),
-        ptr(st.radii), ptr(st.rect), ptr(st.tiles_touched), ptr(st.block_prefix),
-        ctypes.byref(d_host), d_range, stream), "vings_surfel_project")
-    D = int(d_host.value)
+
+    def blend_forward():
+        st.color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        st.allmap = torch.empty((AUX_CHANNELS, H, W), dtype=torch.float32, device=dev)
+        st.final_T = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        st.n_contrib = torch.empty((2, H, W), dtype=torch.int32, device=dev)
+        check(L.vings_surfel_blend_forward(H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom),
+                                           ptr(bg), ptr(mask), ptr(st.color), ptr(st.allmap),
+                                           ptr(st.final_T), ptr(st.n_contrib), stream),
+              "vings_surfel_blend_forward")
+
+    # The instance count D comes back from the projection through the host.  Waiting for it
+    # before the sort is launched leaves the GPU idle once per view, so when an earlier view of
+    # this size is known the sort and the blend are launched at once, sized from that view's
+    # count plus 1/8 and keyed on its depth-bit width; the kernels read the true values from
+    # device memory.  The host then checks the guess and, if it was too small, repeats the two
+    # stages with exact sizes (nothing but their own outputs was written).
+    hint = _D_HINT.get((dev.index, H, W)) if SPECULATE and N > 0 else None
+    done = False
+    if hint is not None and hint[0] > 0:
+        cap = hint[0] + hint[0] // 8 + 4096
+        ws_bytes = int(L.vings_surfel_bin_workspace_bytes(cap))
+        st.keys = torch.empty(cap, dtype=torch.int64, device=dev)
+        st.vals = torch.empty(cap, dtype=torch.int32, device=dev)
+        ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
+        check(L.vings_surfel_project_launch(*project_args, stream), "vings_surfel_project_launch")
+        tail = st.block_prefix.data_ptr() + 4 * (3 * nb + 1)
+        check(L.vings_surfel_bin_speculative(
+            N, H, W, cap, hint[1], tail, ptr(st.depth), ptr(st.rect), ptr(st.tiles_touched),
+            ptr(st.block_prefix), ptr(st.keys), ptr(st.vals), ptr(st.ranges),
+            (ws.data_ptr() + 255) & ~255, ws_bytes, stream), "vings_surfel_bin_speculative")
+        if blend:
+            blend_forward()
+        check(L.vings_surfel_project_wait(ctypes.byref(d_host), d_range), "vings_surfel_project_wait")
+        D = int(d_host.value)
+        bits = int(L.vings_surfel_bin_low_bits(int(d_range[0]), int(d_range[1]))) if D > 0 else 0
+        done = D <= cap and bits <= hint[1]
+        _D_HINT[(dev.index, H, W)] = (D, max(bits, hint[1])) if D > 0 else hint
+    else:
+        check(L.vings_surfel_project(*project_args, ctypes.byref(d_host), d_range, stream),
+              "vings_surfel_project")
+        D = int(d_host.value)
+        if D > 0:
+            _D_HINT[(dev.index, H, W)] = (
+                D, int(L.vings_surfel_bin_low_bits(int(d_range[0]), int(d_range[1]))))
     st.D = D
     global LAST_INSTANCE_COUNT
     LAST_INSTANCE_COUNT = D
-    _D_HINT[dev.index] = D
-    if pre is not None and D <= pre[0]:
-        _, st.keys, st.vals, ws, ws_bytes = pre      # longer than D: entries [D:] are unused
-    else:
+    if not done:
         st.keys = torch.empty(max(D, 1), dtype=torch.int64, device=dev)
         st.vals = torch.empty(max(D, 1), dtype=torch.int32, device=dev)
         ws_bytes = int(L.vings_surfel_bin_workspace_bytes(D))
         ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
-    ws_ptr = (ws.data_ptr() + 255) & ~255
-    check(L.vings_surfel_bin(N, H, W, D, int(d_range[0]), int(d_range[1]), ptr(st.depth),
-                             ptr(st.rect), ptr(st.tiles_touched),
-                             ptr(st.block_prefix), ptr(st.keys), ptr(st.vals), ptr(st.ranges),
-                             ws_ptr, ws_bytes, stream), "vings_surfel_bin")
-    if not blend:
+        check(L.vings_surfel_bin(N, H, W, D, int(d_range[0]), int(d_range[1]), ptr(st.depth),
+                                 ptr(st.rect), ptr(st.tiles_touched), ptr(st.block_prefix),
+                                 ptr(st.keys), ptr(st.vals), ptr(st.ranges),
+                                 (ws.data_ptr() + 255) & ~255, ws_bytes, stream), "vings_surfel_bin")
+        if blend:
+            blend_forward()
+    if not blend or not keep_keys:
         st.keys = None
-        return st, (view, proj, bg, mask, flow)
-    st.color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
-    st.allmap = torch.empty((AUX_CHANNELS, H, W), dtype=torch.float32, device=dev)
-    st.final_T = torch.empty((3, H, W), dtype=torch.float32, device=dev)
-    st.n_contrib = torch.empty((2, H, W), dtype=torch.int32, device=dev)
-    check(L.vings_surfel_blend_forward(H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg),
-                                       ptr(mask), ptr(st.color), ptr(st.allmap), ptr(st.final_T),
-                                       ptr(st.n_contrib), stream), "vings_surfel_blend_forward")
-    if not keep_keys:
-        st.keys = None
-    return st, (view, proj, bg, mask, flow)
+    return st, aux
 
 
 def rasterize_backward(st, aux, means3D, scales, rotations, scale_modifier, g_color, g_allmap,
