@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--views", type=int, default=8, help="keyframes per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dba", action="store_true")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="all ranks share GPU 0 and exchange over gloo: checks the multi-rank "
+                         "path on a one-GPU box; the figure printed is not a benchmark result")
     ap.add_argument("--autograd", action="store_true",
                     help="drive the view step through torch autograd and PyTorch bookkeeping "
                          "instead of the fused C-ABI sequence")
@@ -76,12 +79,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); there is no CPU path")
+    if args.rehearse_gloo:
+        local_rank = 0
+        import faulthandler
+        faulthandler.dump_traceback_later(100, exit=True)      # a stuck rehearsal names its line
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1 and args.gpus == 1, \
         f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
@@ -132,8 +142,13 @@ def main():
                 mapper.finish_view(radii, cur, k, reducer)
             else:
                 mapper.fused_view(cams[i], intr, gts[i], R_host[i], k, reducer)
+        # the record maxima of the window (best keyframe, error score) are merged over the ranks
+        # here, once per window, behind the bundle adjustment
+        finish_records = mapper.sync_records(reducer, async_op=True)
         if dba is not None:
             dba.run()
+        if finish_records is not None:
+            finish_records()
 
     def barrier():
         if world > 1:
@@ -200,7 +215,7 @@ def main():
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" + (" (gloo rehearsal on one GPU: not a benchmark result)" if args.rehearse_gloo else ""),
             "config": {"workload": "BASELINE config 3: 1.0M splats, 8-keyframe window 1920x1080 "
                                    "+ DBA step per GPU",
                        "splats": args.splats, "width": W, "height": H, "views_per_gpu": V,

@@ -302,21 +302,28 @@ int vings_splat_reanchor(int N, float* xyz, float* rotation, const int32_t* owne
 
 /* Exchange between GPU replicas of the splat set (no counterpart in the reference, which is
  * single-GPU: configs/hierarchical/smallcity.yaml:11-13).  After vings_splat_grad_finish with
- * bookkeeping = 0, pack writes per splat one row of 16 floats {g_xyz 3, g_rgb 3, g_opacity,
- * g_scaling 2, g_rotation 4, s0, visible, 0} to be SUMMED over ranks, and two int64 keys
- * {bits(max(s0,0)) << 32 | this_kf, bits(max(s1,0))} to be MAXIMISED over ranks; unpack
- * takes the reduced buffers back into the gradient arrays and the visibility mask and does
- * the add_records bookkeeping (gaussian_model.py:163-168) with the reduced scores. */
+ * bookkeeping = 0, pack writes vings_splat_pack_columns() = 15 planar columns of N floats
+ * {g_xyz 3, g_rgb 3, g_opacity, g_scaling 2, g_rotation 4, s0, visible} (packed[c*N + i]) to
+ * be SUMMED over ranks after every view; unpack takes the summed buffer back into the
+ * gradient arrays and the visibility mask and adds the summed s0 to the score records
+ * (add_records, gaussian_model.py:163-168).  The two record maxima that no view step reads
+ * (best keyframe per splat, error score) are not exchanged per view: pack folds
+ * {bits(max(s0,0)) << 32 | this_kf, bits(max(s1,0))} into the running maximum held in
+ * record_keys [N,2] (zero it once); when the records are needed the caller MAXIMISES
+ * record_keys over ranks and vings_splat_merge_records folds it into local_scores[:,1],
+ * kf_max_scores and kf_id and zeroes it again. */
+int vings_splat_pack_columns(void);
 int vings_splat_pack_exchange(int N, const float* g_xyz, const float* g_rgb,
                               const float* g_opacity, const float* g_scaling,
                               const float* g_rotation, const uint8_t* visible,
                               const float* cur_scores, int64_t this_kf, float* packed,
-                              int64_t* keys, void* stream);
-int vings_splat_unpack_exchange(int N, const float* packed, const int64_t* keys,
-                                float* global_scores, float* local_scores, float* kf_max_scores,
-                                int64_t* kf_id, float* g_xyz, float* g_rgb, float* g_opacity,
-                                float* g_scaling, float* g_rotation, uint8_t* visible,
-                                void* stream);
+                              int64_t* record_keys, void* stream);
+int vings_splat_unpack_exchange(int N, const float* packed, float* global_scores,
+                                float* local_scores, float* g_xyz, float* g_rgb,
+                                float* g_opacity, float* g_scaling, float* g_rotation,
+                                uint8_t* visible, void* stream);
+int vings_splat_merge_records(int N, int64_t* record_keys, float* local_scores,
+                              float* kf_max_scores, int64_t* kf_id, void* stream);
 
 /* ------------------------------------------------------------------------
  * Mapping loss of one rendered view and its gradient w.r.t. the rasteriser

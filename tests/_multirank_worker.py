@@ -33,6 +33,12 @@ def main():
         radii, cur = a.backward_view(w2c, intr, gt)
         a.finish_view(radii, cur, k, red)
         b.fused_view(harness.view_settings(w2c, intr), intr, gt, w2c[:3, :3].cpu(), k, red)
+        if s == 0:
+            a.sync_records(red)                    # blocking form after the first step ...
+            b.sync_records(red)
+    for m in (a, b):                               # ... and the overlapped form at the end
+        fin = m.sync_records(red, async_op=True)
+        fin()
     torch.cuda.synchronize()
     state = {"rank": rank}
     for name, m in (("autograd", a), ("fused", b)):
@@ -40,6 +46,7 @@ def main():
         state[name]["global_scores"] = m.global_scores.cpu()
         state[name]["local_scores"] = m.local_scores.cpu()
         state[name]["kf_id"] = m.globalkf_id.cpu()
+        state[name]["kf_max"] = m.globalkf_max_scores.cpu()
     state["raw"] = {k: raw[k].clone() for k in a.NAMES}
     torch.save(state, f"{out_path}.rank{rank}.pt")
     dist.barrier()

@@ -117,7 +117,13 @@ def _reducer_worker(rank, world, port, n, out_dir):
     cur = torch.rand(n, 2, generator=g)
     vis = torch.rand(n, generator=g) > 0.5
     red = GradReducer(n, torch.device("cpu"), world)
-    vis_any, s0, s1, best, best_kf = red.reduce(grads, cur, vis, 10 + rank)
+    from vings_mono_amd import parallel
+    vis_any, s0 = red.reduce(grads, cur, vis)
+    # two views per rank folded into the running keys, then one MAX over the ranks
+    cur2 = torch.rand(n, 2, generator=g)
+    keys = torch.maximum(parallel.record_keys(cur, 10 + rank), parallel.record_keys(cur2, 20 + rank))
+    red.all_reduce_record_keys(keys)
+    best, best_kf, s1 = parallel.split_record_keys(keys)
     torch.save({"grads": grads, "vis": vis_any, "s0": s0, "s1": s1, "best": best, "kf": best_kf},
                os.path.join(out_dir, f"r{rank}.pt"))
     dist.destroy_process_group()
@@ -138,16 +144,19 @@ def test_grad_reducer_two_ranks_gloo(tmp_path):
             exp_g[k] += torch.randn(n, w, generator=g)
         curs.append(torch.rand(n, 2, generator=g))
         viss.append(torch.rand(n, generator=g) > 0.5)
+        curs.append(torch.rand(n, 2, generator=g))       # the rank's second view
+    kfs = torch.tensor([10, 20, 11, 21])                 # view order in `curs`
+    all0 = torch.stack([c[:, 0] for c in curs])          # [4, n]
+    all1 = torch.stack([c[:, 1] for c in curs])
     for r in range(world):
         for k in widths:
             torch.testing.assert_close(res[r]["grads"][k], exp_g[k])
         assert torch.equal(res[r]["vis"], viss[0] | viss[1])
-        torch.testing.assert_close(res[r]["s0"], curs[0][:, 0] + curs[1][:, 0])
-        assert torch.equal(res[r]["s1"], torch.maximum(curs[0][:, 1], curs[1][:, 1]))
-        assert torch.equal(res[r]["best"], torch.maximum(curs[0][:, 0], curs[1][:, 0]))
-        exp_kf = torch.where(curs[1][:, 0] >= curs[0][:, 0], 11, 10)
-        # ties go to the larger keyframe id (max over the packed key)
-        assert torch.equal(res[r]["kf"], exp_kf)
+        torch.testing.assert_close(res[r]["s0"], curs[0][:, 0] + curs[2][:, 0])
+        assert torch.equal(res[r]["s1"], all1.max(0).values)
+        assert torch.equal(res[r]["best"], all0.max(0).values)
+        # random float scores: no ties, the keyframe of the best view comes with it
+        assert torch.equal(res[r]["kf"], kfs[all0.argmax(0)])
     # replicas agree bit for bit
     for k in widths:
         assert torch.equal(res[0]["grads"][k], res[1]["grads"][k])
@@ -158,8 +167,17 @@ def test_grad_reducer_single_rank_is_identity():
     red = GradReducer(7, torch.device("cpu"), 1)
     cur = torch.rand(7, 2)
     vis = torch.tensor([True, False] * 3 + [True])
-    out = red.reduce({}, cur, vis, 4)
-    assert out[0] is vis and torch.equal(out[1], cur[:, 0]) and torch.equal(out[4], torch.full((7,), 4))
+    out = red.reduce({}, cur, vis)
+    assert out[0] is vis and torch.equal(out[1], cur[:, 0])
+    assert red.all_reduce_record_keys(torch.zeros(7, 2, dtype=torch.int64)) is None
+
+
+def test_record_keys_round_trip():
+    from vings_mono_amd import parallel
+    cur = torch.tensor([[0.5, 2.0], [-1.0, 0.0], [3e-9, 7.5]])
+    best, kf, s1 = parallel.split_record_keys(parallel.record_keys(cur, 123456))
+    assert torch.equal(best, cur[:, 0].clamp(min=0)) and torch.equal(s1, cur[:, 1].clamp(min=0))
+    assert torch.equal(kf, torch.full((3,), 123456))
 
 
 def test_dropin_modules_expose_reference_names():

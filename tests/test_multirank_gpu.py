@@ -32,7 +32,7 @@ def test_two_rank_view_steps(tmp_path):
     s1 = torch.load(out + ".rank1.pt", weights_only=True)
     names = ("_xyz", "_rgb", "_opacity", "_scaling", "_rotation")
     for impl in ("autograd", "fused"):
-        for k in names + ("global_scores", "local_scores", "kf_id"):
+        for k in names + ("global_scores", "local_scores", "kf_id", "kf_max"):
             assert torch.equal(s0[impl][k], s1[impl][k]), f"{impl}: replicas differ in {k}"
     for k in names:
         ua = s0["autograd"][k] - s0["raw"][k]
@@ -40,6 +40,9 @@ def test_two_rank_view_steps(tmp_path):
         scale = float(ua.abs().max())
         assert scale > 0, k
         assert float((ua - ub).abs().max()) <= 2e-2 * scale, k
-    for k in ("global_scores", "local_scores"):
+    # the record maxima were merged over the ranks (once mid-run, once at the end)
+    assert float(s0["fused"]["kf_max"].max()) > 0 and float(s0["fused"]["local_scores"][:, 1].max()) > 0
+    assert len(torch.unique(s0["fused"]["kf_id"])) > 1
+    for k in ("global_scores", "local_scores", "kf_max"):
         scale = float(s0["autograd"][k].abs().max())
         assert float((s0["autograd"][k] - s0["fused"][k]).abs().max()) <= 1e-4 * scale, k

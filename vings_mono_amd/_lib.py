@@ -50,7 +50,9 @@ _SIGNATURES = {
     "vings_splat_top3_update": (_c.c_int, [_c.c_int, _P, _c.c_int, _P, _P, _P]),
     "vings_splat_reanchor": (_c.c_int, [_c.c_int, _P, _P, _P] + [_c.c_int] * 4 + [_P] * 5),
     "vings_splat_pack_exchange": (_c.c_int, [_c.c_int] + [_P] * 7 + [_c.c_int64] + [_P] * 3),
-    "vings_splat_unpack_exchange": (_c.c_int, [_c.c_int] + [_P] * 13),
+    "vings_splat_unpack_exchange": (_c.c_int, [_c.c_int] + [_P] * 10),
+    "vings_splat_pack_columns": (_c.c_int, []),
+    "vings_splat_merge_records": (_c.c_int, [_c.c_int] + [_P] * 5),
     "vings_depth_covariance": (_c.c_int, [_c.c_int] * 4 + [_P] * 8),
     "vings_upsample_maps": (_c.c_int, [_c.c_int] * 3 + [_P, _P, _c.c_int, _P, _P, _P]),
     "vings_package_workspace_bytes": (_c.c_size_t, [_c.c_int]),

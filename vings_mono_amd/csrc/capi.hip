@@ -15,7 +15,7 @@ void set_error(const char* fmt, ...) {
 }  // namespace vings
 
 extern "C" const char* vings_last_error(void) { return vings::g_err; }
-extern "C" int vings_abi_version(void) { return 2; }
+extern "C" int vings_abi_version(void) { return 3; }
 
 // ---------------------------------------------------------------------------
 // Per-kernel timing with HIP events recorded on the caller's stream.

@@ -86,57 +86,71 @@ __global__ __launch_bounds__(256) void splat_grad_finish_kernel(int N, FinishArg
     reinterpret_cast<float4*>(a.g_rotation)[i] = out;
 }
 
-// ---- exchange between GPU replicas (one row of 16 floats + two int64 keys per splat) ----
-// packed[i] = {g_xyz 3, g_rgb 3, g_opacity 1, g_scaling 2, g_rotation 4, s0, visible, 0}: summed
-// over ranks.  keys[i] = {bits(max(s0,0)) << 32 | keyframe, bits(max(s1,0))}: maximised over
-// ranks (non-negative floats order like their bit patterns).
+// ---- exchange between GPU replicas ----
+// packed is planar, 15 columns of N floats: {g_xyz 3, g_rgb 3, g_opacity 1, g_scaling 2,
+// g_rotation 4, s0, visible}; it is summed over ranks after every view.  The two bookkeeping
+// maxima no view step reads (best keyframe, error score) stay rank-local between merges:
+// keys[i] = {bits(max(s0,0)) << 32 | keyframe, bits(max(s1,0))} holds their running maximum
+// (non-negative floats order like their bit patterns), is maximised over ranks whenever the
+// records are needed and then folded into the record arrays by splat_merge_records_kernel.
+constexpr int kPackColumns = 15;
+
 struct ExchangeArgs {
     float* g_xyz; float* g_rgb; float* g_opacity; float* g_scaling; float* g_rotation;
     uint8_t* visible;
-    float* packed; long long* keys;
+    float* packed;
 };
 
 __global__ __launch_bounds__(256) void splat_pack_kernel(int N, ExchangeArgs a,
                                                          const float* __restrict__ cur_scores,
-                                                         long long this_kf) {
+                                                         long long this_kf,
+                                                         long long* __restrict__ keys) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
-    const float s0 = cur_scores[2 * i], s1 = cur_scores[2 * i + 1];
-    float4* row = reinterpret_cast<float4*>(a.packed) + 4 * (size_t)i;
+    const float2 s = reinterpret_cast<const float2*>(cur_scores)[i];
     const float2 sc = reinterpret_cast<const float2*>(a.g_scaling)[i];
     const float4 q = reinterpret_cast<const float4*>(a.g_rotation)[i];
-    row[0] = make_float4(a.g_xyz[3 * i], a.g_xyz[3 * i + 1], a.g_xyz[3 * i + 2], a.g_rgb[3 * i]);
-    row[1] = make_float4(a.g_rgb[3 * i + 1], a.g_rgb[3 * i + 2], a.g_opacity[i], sc.x);
-    row[2] = make_float4(sc.y, q.x, q.y, q.z);
-    row[3] = make_float4(q.w, s0, a.visible[i] ? 1.f : 0.f, 0.f);
-    const long long b0 = (long long)__float_as_uint(fmaxf(s0, 0.f));
-    const long long b1 = (long long)__float_as_uint(fmaxf(s1, 0.f));
-    a.keys[2 * i] = (b0 << 32) | (this_kf & 0xFFFFFFFFll);
-    a.keys[2 * i + 1] = b1;
+    const float v[kPackColumns] = {a.g_xyz[3 * i], a.g_xyz[3 * i + 1], a.g_xyz[3 * i + 2],
+                                   a.g_rgb[3 * i], a.g_rgb[3 * i + 1], a.g_rgb[3 * i + 2],
+                                   a.g_opacity[i], sc.x, sc.y, q.x, q.y, q.z, q.w, s.x,
+                                   a.visible[i] ? 1.f : 0.f};
+#pragma unroll
+    for (int c = 0; c < kPackColumns; ++c) a.packed[(size_t)c * N + i] = v[c];
+    const long long b0 = (long long)__float_as_uint(fmaxf(s.x, 0.f));
+    const long long b1 = (long long)__float_as_uint(fmaxf(s.y, 0.f));
+    const long long k0 = (b0 << 32) | (this_kf & 0xFFFFFFFFll);
+    keys[2 * i] = max(keys[2 * i], k0);
+    keys[2 * i + 1] = max(keys[2 * i + 1], b1);
 }
 
 __global__ __launch_bounds__(256) void splat_unpack_kernel(int N, ExchangeArgs a,
                                                            float* __restrict__ global_scores,
-                                                           float* __restrict__ local_scores,
-                                                           float* __restrict__ kf_max_scores,
-                                                           int64_t* __restrict__ kf_id) {
+                                                           float* __restrict__ local_scores) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
-    const float4* row = reinterpret_cast<const float4*>(a.packed) + 4 * (size_t)i;
-    const float4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
-    a.g_xyz[3 * i] = r0.x; a.g_xyz[3 * i + 1] = r0.y; a.g_xyz[3 * i + 2] = r0.z;
-    a.g_rgb[3 * i] = r0.w; a.g_rgb[3 * i + 1] = r1.x; a.g_rgb[3 * i + 2] = r1.y;
-    a.g_opacity[i] = r1.z;
-    reinterpret_cast<float2*>(a.g_scaling)[i] = make_float2(r1.w, r2.x);
-    reinterpret_cast<float4*>(a.g_rotation)[i] = make_float4(r2.y, r2.z, r2.w, r3.x);
-    a.visible[i] = r3.z > 0.f ? 1 : 0;
-    const float s0_sum = r3.y;
-    const long long k0 = a.keys[2 * i], k1 = a.keys[2 * i + 1];
+    float v[kPackColumns];
+#pragma unroll
+    for (int c = 0; c < kPackColumns; ++c) v[c] = a.packed[(size_t)c * N + i];
+    a.g_xyz[3 * i] = v[0]; a.g_xyz[3 * i + 1] = v[1]; a.g_xyz[3 * i + 2] = v[2];
+    a.g_rgb[3 * i] = v[3]; a.g_rgb[3 * i + 1] = v[4]; a.g_rgb[3 * i + 2] = v[5];
+    a.g_opacity[i] = v[6];
+    reinterpret_cast<float2*>(a.g_scaling)[i] = make_float2(v[7], v[8]);
+    reinterpret_cast<float4*>(a.g_rotation)[i] = make_float4(v[9], v[10], v[11], v[12]);
+    a.visible[i] = v[14] > 0.f ? 1 : 0;
+    local_scores[2 * i] += v[13];
+    global_scores[2 * i] = fminf(fmaxf(global_scores[2 * i] + v[13], 0.f), 1e4f);
+}
+
+__global__ __launch_bounds__(256) void splat_merge_records_kernel(int N, long long* __restrict__ keys,
+                                                                  float* __restrict__ local_scores,
+                                                                  float* __restrict__ kf_max_scores,
+                                                                  int64_t* __restrict__ kf_id) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const long long k0 = keys[2 * i], k1 = keys[2 * i + 1];
+    keys[2 * i] = 0; keys[2 * i + 1] = 0;
     const float best = __uint_as_float((uint32_t)(k0 >> 32));
-    const float s1_max = __uint_as_float((uint32_t)k1);
-    local_scores[2 * i] += s0_sum;
-    global_scores[2 * i] = fminf(fmaxf(global_scores[2 * i] + s0_sum, 0.f), 1e4f);
-    local_scores[2 * i + 1] = fmaxf(local_scores[2 * i + 1], s1_max);
+    local_scores[2 * i + 1] = fmaxf(local_scores[2 * i + 1], __uint_as_float((uint32_t)k1));
     if (kf_max_scores[i] < best) { kf_max_scores[i] = best; kf_id[i] = (int64_t)(k0 & 0xFFFFFFFFll); }
 }
 
@@ -195,53 +209,65 @@ extern "C" int vings_splat_grad_finish(
 }
 
 static int exchange_args(int N, float* g_xyz, float* g_rgb, float* g_opacity, float* g_scaling,
-                         float* g_rotation, uint8_t* visible, float* packed, int64_t* keys,
-                         ExchangeArgs* a) {
+                         float* g_rotation, uint8_t* visible, float* packed, ExchangeArgs* a) {
     VINGS_REQUIRE(N >= 0, "sizes");
     if (N == 0) return VINGS_OK;
-    VINGS_REQUIRE(g_xyz && g_rgb && g_opacity && g_scaling && g_rotation && visible && packed && keys,
+    VINGS_REQUIRE(g_xyz && g_rgb && g_opacity && g_scaling && g_rotation && visible && packed,
                   "null pointer");
-    VINGS_REQUIRE((((uintptr_t)packed | (uintptr_t)g_rotation) & 15) == 0 &&
-                      ((uintptr_t)g_scaling & 7) == 0 && ((uintptr_t)keys & 7) == 0,
-                  "packed / rotation arrays must be 16-byte aligned, scaling / keys 8-byte aligned");
+    VINGS_REQUIRE(((uintptr_t)g_rotation & 15) == 0 && ((uintptr_t)g_scaling & 7) == 0,
+                  "rotation arrays must be 16-byte aligned, scaling arrays 8-byte aligned");
     a->g_xyz = g_xyz; a->g_rgb = g_rgb; a->g_opacity = g_opacity; a->g_scaling = g_scaling;
     a->g_rotation = g_rotation; a->visible = visible; a->packed = packed;
-    a->keys = reinterpret_cast<long long*>(keys);
     return VINGS_OK;
 }
+
+extern "C" int vings_splat_pack_columns(void) { return kPackColumns; }
 
 extern "C" int vings_splat_pack_exchange(int N, const float* g_xyz, const float* g_rgb,
                                          const float* g_opacity, const float* g_scaling,
                                          const float* g_rotation, const uint8_t* visible,
                                          const float* cur_scores, int64_t this_kf, float* packed,
-                                         int64_t* keys, void* stream) {
+                                         int64_t* record_keys, void* stream) {
     ExchangeArgs a;
     const int rc = exchange_args(N, const_cast<float*>(g_xyz), const_cast<float*>(g_rgb),
                                  const_cast<float*>(g_opacity), const_cast<float*>(g_scaling),
                                  const_cast<float*>(g_rotation), const_cast<uint8_t*>(visible),
-                                 packed, keys, &a);
+                                 packed, &a);
     if (rc != VINGS_OK || N == 0) return rc;
-    VINGS_REQUIRE(cur_scores, "null pointer");
+    VINGS_REQUIRE(cur_scores && record_keys, "null pointer");
+    VINGS_REQUIRE((((uintptr_t)cur_scores | (uintptr_t)record_keys) & 7) == 0,
+                  "score and key arrays must be 8-byte aligned");
     ProfScope prof(PROF_GLUE, (hipStream_t)stream);
-    splat_pack_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(N, a, cur_scores,
-                                                                     (long long)this_kf);
+    splat_pack_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(
+        N, a, cur_scores, (long long)this_kf, reinterpret_cast<long long*>(record_keys));
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }
 
-extern "C" int vings_splat_unpack_exchange(int N, const float* packed, const int64_t* keys,
-                                           float* global_scores, float* local_scores,
-                                           float* kf_max_scores, int64_t* kf_id, float* g_xyz,
-                                           float* g_rgb, float* g_opacity, float* g_scaling,
-                                           float* g_rotation, uint8_t* visible, void* stream) {
+extern "C" int vings_splat_unpack_exchange(int N, const float* packed, float* global_scores,
+                                           float* local_scores, float* g_xyz, float* g_rgb,
+                                           float* g_opacity, float* g_scaling, float* g_rotation,
+                                           uint8_t* visible, void* stream) {
     ExchangeArgs a;
     const int rc = exchange_args(N, g_xyz, g_rgb, g_opacity, g_scaling, g_rotation, visible,
-                                 const_cast<float*>(packed), const_cast<int64_t*>(keys), &a);
+                                 const_cast<float*>(packed), &a);
     if (rc != VINGS_OK || N == 0) return rc;
-    VINGS_REQUIRE(global_scores && local_scores && kf_max_scores && kf_id, "null pointer");
+    VINGS_REQUIRE(global_scores && local_scores, "null pointer");
     ProfScope prof(PROF_GLUE, (hipStream_t)stream);
-    splat_unpack_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(
-        N, a, global_scores, local_scores, kf_max_scores, kf_id);
+    splat_unpack_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(N, a, global_scores,
+                                                                       local_scores);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}
+
+extern "C" int vings_splat_merge_records(int N, int64_t* record_keys, float* local_scores,
+                                         float* kf_max_scores, int64_t* kf_id, void* stream) {
+    VINGS_REQUIRE(N >= 0, "sizes");
+    if (N == 0) return VINGS_OK;
+    VINGS_REQUIRE(record_keys && local_scores && kf_max_scores && kf_id, "null pointer");
+    ProfScope prof(PROF_GLUE, (hipStream_t)stream);
+    splat_merge_records_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(
+        N, reinterpret_cast<long long*>(record_keys), local_scores, kf_max_scores, kf_id);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }

@@ -248,19 +248,57 @@ class SurfelMapper:
             grads[k].mul_(w)
         vis = (radii > 0) & (~self.stable_mask)
         if reducer is not None and reducer.world > 1:
-            vis, s0_sum, s1_max, best, best_kf = reducer.reduce(grads, cur, vis, kf_id)
+            from . import parallel
+            vis, s0_sum = reducer.reduce(grads, cur, vis)
+            self._pending_keys = torch.maximum(self._record_keys(), parallel.record_keys(cur, kf_id))
+            self.local_scores[:, 0] += s0_sum
+            self.global_scores[:, 0] = (self.global_scores[:, 0] + s0_sum).clamp(0.0, 1e4)
         else:
-            s0_sum, s1_max, best = s0, cur[:, 1], s0
-            best_kf = torch.full_like(self.globalkf_id, kf_id)
-        self.local_scores[:, 0] += s0_sum
-        self.global_scores[:, 0] = (self.global_scores[:, 0] + s0_sum).clamp(0.0, 1e4)
-        self.local_scores[:, 1] = torch.maximum(self.local_scores[:, 1], s1_max)
-        replace = self.globalkf_max_scores < best
-        self.globalkf_max_scores = torch.where(replace, best, self.globalkf_max_scores)
-        self.globalkf_id = torch.where(replace, best_kf, self.globalkf_id)
+            self.local_scores[:, 0] += s0
+            self.global_scores[:, 0] = (self.global_scores[:, 0] + s0).clamp(0.0, 1e4)
+            self.local_scores[:, 1] = torch.maximum(self.local_scores[:, 1], cur[:, 1])
+            replace = self.globalkf_max_scores < s0
+            self.globalkf_max_scores = torch.where(replace, s0, self.globalkf_max_scores)
+            self.globalkf_id = torch.where(replace, torch.full_like(self.globalkf_id, kf_id),
+                                           self.globalkf_id)
         self.optimizer.step(vis, self.n)
         self.optimizer.zero_grad(set_to_none=False)
         self._last_radii = radii
+
+    # ------------------------------------------------------------------ multi-GPU records
+    def _record_keys(self):
+        """Running maximum of this rank's (best score | keyframe, error score) keys since the
+        last sync_records; int64 [N,2]."""
+        if getattr(self, "_pending_keys", None) is None:
+            self._pending_keys = torch.zeros((self.n, 2), dtype=torch.int64, device=self.device)
+        return self._pending_keys
+
+    def sync_records(self, reducer, async_op=False):
+        """Folds the record maxima the ranks gathered since the last call into
+        local_scores[:,1], globalkf_max_scores and globalkf_id (one MAX all-reduce).  The view
+        steps do not read these three, so a multi-GPU job calls this once per window and before
+        anything that does (storage control, loop closure, checkpoints); with one rank the
+        records are always current and this does nothing.  With async_op the collective is only
+        started and a function that completes the merge is returned (None when there is nothing
+        to do), so independent work can be queued in between."""
+        if reducer is None or reducer.world == 1 or getattr(self, "_pending_keys", None) is None:
+            return None
+        from . import _lib
+        keys = self._pending_keys
+        work = reducer.all_reduce_record_keys(keys, async_op=async_op)
+
+        def finish():
+            if async_op:
+                work.wait()
+            _lib.check(_lib.lib().vings_splat_merge_records(
+                self.n, _lib.ptr(keys), _lib.ptr(self.local_scores),
+                _lib.ptr(self.globalkf_max_scores), _lib.ptr(self.globalkf_id),
+                _lib.stream_ptr(self.device)), "vings_splat_merge_records")
+
+        if async_op:
+            return finish
+        finish()
+        return None
 
     # ------------------------------------------------------------------ fused view step
     def _fused_buffers(self):
@@ -307,15 +345,14 @@ class SurfelMapper:
                 "vings_splat_grad_finish")
             vis = fb["vis"]
             if not single:
-                # pack -> SUM / MAX all-reduce over the replicas -> unpack + bookkeeping
+                # pack -> SUM all-reduce over the replicas -> unpack + score sums
                 grad_ptrs = [ptr(g[k]) for k in self.NAMES]
                 _lib.check(L.vings_splat_pack_exchange(
                     n, *grad_ptrs, ptr(vis), ptr(cur), int(kf_id), ptr(reducer.fbuf),
-                    ptr(reducer.ibuf), stream), "vings_splat_pack_exchange")
+                    ptr(self._record_keys()), stream), "vings_splat_pack_exchange")
                 reducer.all_reduce_packed()
                 _lib.check(L.vings_splat_unpack_exchange(
-                    n, ptr(reducer.fbuf), ptr(reducer.ibuf), ptr(self.global_scores),
-                    ptr(self.local_scores), ptr(self.globalkf_max_scores), ptr(self.globalkf_id),
+                    n, ptr(reducer.fbuf), ptr(self.global_scores), ptr(self.local_scores),
                     *grad_ptrs, ptr(vis), stream), "vings_splat_unpack_exchange")
             self.optimizer.step(vis, n)
         self.last_loss = loss_vec[0]

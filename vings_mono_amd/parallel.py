@@ -4,23 +4,42 @@ replica per GPU, the keyframes of a window dealt out over the ranks.
 The reference is single-GPU (every config sets device.tracker = device.mapper =
 cuda:0, e.g. /root/reference/configs/hierarchical/smallcity.yaml:11-13), so
 this exchange step has no counterpart there.  Per optimisation step every
-rank renders and back-propagates its own view, then two collectives keep the
+rank renders and back-propagates its own view, then one collective keeps the
 replicas bit-identical:
 
-  SUM  float32 [N,16]: 14 score-weighted parameter gradients, the importance
-       score of the view, and the visibility flag
-  MAX  int64   [N,2] : (importance score bits << 32 | keyframe id) for the
-       best-keyframe bookkeeping, and the error-score bits for its running max
+  SUM  float32 [15,N] (planar): 13 score-weighted parameter gradients, the
+       importance score of the view and the visibility flag
+
+The two record maxima that no view step reads (best keyframe per splat, error
+score) stay rank-local between merges: every view folds
+(importance score bits << 32 | keyframe id, error score bits) into a running
+int64 [N,2] maximum, and `SurfelMapper.sync_records` maximises that over the
+ranks (MAX all-reduce) once per window, or whenever the records are read.
 
 Both run over RCCL on the GPUs of one node (backend "nccl"); the same code runs
 over gloo on CPU tensors in the tests.
 """
 import torch
 
-PACK_WIDTH = 16
+PACK_WIDTH = 15
 _SLICES = {"_xyz": (0, 3), "_rgb": (3, 6), "_opacity": (6, 7), "_scaling": (7, 9),
            "_rotation": (9, 13)}
 _COL_SCORE0, _COL_VIS = 13, 14
+
+
+def record_keys(cur, kf_id):
+    """int64 [N,2] = (bits(max(s0,0)) << 32 | kf_id, bits(max(s1,0))): non-negative floats order
+    like their bit patterns, so an integer MAX picks the best score and, with it, its keyframe
+    (ties go to the larger keyframe id)."""
+    s0 = cur[:, 0].contiguous().clamp(min=0).view(torch.int32).to(torch.int64)
+    s1 = cur[:, 1].contiguous().clamp(min=0).view(torch.int32).to(torch.int64)
+    return torch.stack([(s0 << 32) | int(kf_id), s1], dim=1)
+
+
+def split_record_keys(keys):
+    """(best score0 [N] float32, its keyframe id [N] int64, max score1 [N] float32)."""
+    best = (keys[:, 0] >> 32).to(torch.int32).view(torch.float32)
+    return best, keys[:, 0] & 0xFFFFFFFF, keys[:, 1].to(torch.int32).view(torch.float32)
 
 
 def shard_views(n_views, world, rank):
@@ -33,43 +52,43 @@ class GradReducer:
     def __init__(self, n, device, world, group=None):
         self.n, self.world, self.group = n, world, group
         if world > 1:
-            self.fbuf = torch.zeros((n, PACK_WIDTH), dtype=torch.float32, device=device)
-            self.ibuf = torch.zeros((n, 2), dtype=torch.int64, device=device)
+            self.fbuf = torch.zeros((PACK_WIDTH, n), dtype=torch.float32, device=device)
+
+    def _ready(self, t):
+        """gloo stages device tensors through host memory; on this ROCm stack that copy stalls
+        for good when it is queued behind kernels still running, so wait for them first.  RCCL
+        runs on the device and orders itself after the current stream."""
+        import torch.distributed as dist
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            torch.cuda.current_stream(t.device).synchronize()
 
     def all_reduce_packed(self):
-        """SUM over `fbuf` and MAX over `ibuf`, both already filled on the device (the fused
-        view step packs them with one kernel); the two collectives run concurrently."""
+        """SUM over `fbuf`, already filled on the device (the fused view step packs it with one
+        kernel)."""
         import torch.distributed as dist
-        h1 = dist.all_reduce(self.fbuf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        h2 = dist.all_reduce(self.ibuf, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
-        h1.wait()
-        h2.wait()
+        self._ready(self.fbuf)
+        dist.all_reduce(self.fbuf, op=dist.ReduceOp.SUM, group=self.group)
 
-    def reduce(self, grads, cur, vis_local, kf_id):
-        """grads: dict name -> [N,M] tensor (updated in place with the sum over ranks).
-        Returns (vis_any[N] bool, score0_sum[N], score1_max[N], best_score0[N], best_kf[N])."""
+    def all_reduce_record_keys(self, keys, async_op=False):
+        """MAX over the ranks of the running record keys ([N,2] int64), in place.  With
+        async_op the collective's work handle is returned (wait() before reading `keys`)."""
         if self.world == 1:
-            return (vis_local, cur[:, 0], cur[:, 1], cur[:, 0],
-                    torch.full((self.n,), kf_id, dtype=torch.int64, device=cur.device))
+            return None
         import torch.distributed as dist
+        self._ready(keys)
+        return dist.all_reduce(keys, op=dist.ReduceOp.MAX, group=self.group, async_op=async_op)
+
+    def reduce(self, grads, cur, vis_local):
+        """grads: dict name -> [N,M] tensor (updated in place with the sum over ranks).
+        Returns (vis_any [N] bool, score0_sum [N])."""
+        if self.world == 1:
+            return vis_local, cur[:, 0]
         f = self.fbuf
         for name, (a, b) in _SLICES.items():
-            f[:, a:b] = grads[name].reshape(self.n, b - a)
-        f[:, _COL_SCORE0] = cur[:, 0]
-        f[:, _COL_VIS] = vis_local.to(torch.float32)
-        f[:, 15] = 0
-        i = self.ibuf
-        s0 = cur[:, 0].contiguous().clamp(min=0).view(torch.int32).to(torch.int64)
-        s1 = cur[:, 1].contiguous().clamp(min=0).view(torch.int32).to(torch.int64)
-        i[:, 0] = (s0 << 32) | int(kf_id)
-        i[:, 1] = s1
-        h1 = dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        h2 = dist.all_reduce(i, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
-        h1.wait()
-        h2.wait()
+            f[a:b] = grads[name].reshape(self.n, b - a).t()
+        f[_COL_SCORE0] = cur[:, 0]
+        f[_COL_VIS] = vis_local.to(torch.float32)
+        self.all_reduce_packed()
         for name, (a, b) in _SLICES.items():
-            grads[name].copy_(f[:, a:b].reshape(grads[name].shape))
-        best_score = (i[:, 0] >> 32).to(torch.int32).view(torch.float32)
-        best_kf = i[:, 0] & 0xFFFFFFFF
-        score1 = i[:, 1].to(torch.int32).view(torch.float32)
-        return f[:, _COL_VIS] > 0, f[:, _COL_SCORE0].clone(), score1, best_score, best_kf
+            grads[name].copy_(f[a:b].t().reshape(grads[name].shape))
+        return f[_COL_VIS] > 0, f[_COL_SCORE0].clone()

@@ -8,6 +8,7 @@ ABI of include/vings_hip.h; torch only provides device memory, the current
 stream and the autograd hook.
 """
 import ctypes
+import os
 from typing import NamedTuple, Optional
 
 import torch
@@ -80,7 +81,7 @@ def view_importance(means3D, colors, opacities, scales, rotations, settings, out
     return out, st.radii
 
 
-SPECULATE = True   # launch sort + blend before the host has the instance count (see _forward)
+SPECULATE = os.environ.get("VINGS_SPECULATE", "1") != "0"   # launch sort + blend before the host has the instance count (see _forward)
 _D_HINT = {}       # (device index, H, W) -> (instance count, depth key bits) of the latest view
 
 
