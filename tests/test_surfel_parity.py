@@ -284,11 +284,13 @@ def test_sparse_adam_parity(oracle32, N, offset):
         np.testing.assert_array_equal(opt.state[params[k]]["exp_avg_sq"].cpu().numpy(), ref_v[k])
 
 
-def _forward_state(raw, W, H, view=0, keep_keys=True):
+def _forward_state(raw, W, H, view=0, keep_keys=True, look_away=False):
     dev = torch.device("cuda:0")
     from vings_mono_amd import harness
     intr = synth.intrinsic_for(W, H)
     w2c = torch.linalg.inv(synth.window_poses(max(view + 1, 1))[view]).to(dev)
+    if look_away:                                   # half a turn about the camera's y axis
+        w2c = torch.diag(torch.tensor([-1.0, 1.0, -1.0, 1.0], device=dev)) @ w2c
     act = synth.activate({k: v.to(dev) for k, v in raw.items()})
     return surfel.rasterize_forward(act["means3D"], act["colors"], act["opacities"].contiguous(),
                                     act["scales"].contiguous(), act["rotations"].contiguous(),
@@ -316,6 +318,7 @@ def test_speculative_launch_equals_exact_launch():
         want_small = _forward_state(small, W, H)
         want_small1 = _forward_state(small, W, H, view=1)
         want_big = _forward_state(big, W, H)
+        want_none = _forward_state(small, W, H, look_away=True)
     finally:
         surfel.SPECULATE = True
     surfel._D_HINT.clear()
@@ -326,3 +329,6 @@ def test_speculative_launch_equals_exact_launch():
     _same_state(want_big, _forward_state(big, W, H))            # count and key width too small
     _same_state(want_big, _forward_state(big, W, H))            # guess fits again
     _same_state(want_small, _forward_state(small, W, H))        # guess far too large: still exact
+    assert want_none.D == 0
+    _same_state(want_none, _forward_state(small, W, H, look_away=True))   # nothing in view
+    _same_state(want_small, _forward_state(small, W, H))        # the hint survives an empty view
