@@ -222,6 +222,21 @@ int vings_splat_grad_finish(int N, const float* opacities, const float* scales,
                             float* g_xyz, float* g_rgb, float* g_opacity, float* g_scaling,
                             float* g_rotation, uint8_t* visible, void* stream);
 
+/* vings_surfel_project_backward and vings_splat_grad_finish in one launch, for the mapper's view
+ * step (gaussian_base.py:385-403 straight after the rasteriser backward of
+ * rasterize_points.cu / backward.cu preprocess): the gradients w.r.t. the activated
+ * parameters stay in registers.  scales / rotations / opacities are the ACTIVATED values the
+ * forward pass was given, raw_rotation the stored quaternion; the g_* and visible outputs
+ * and the bookkeeping are exactly those of vings_splat_grad_finish (bit-identical).
+ * scores_grad [N,2] (optional) receives the view's two scores as the unfused call does. */
+int vings_surfel_project_backward_finish(
+    int N, int H, int W, float scale_modifier, const float* means3D, const float* scales,
+    const float* rotations, const float* viewmatrix, const float* projmatrix, const int32_t* radii,
+    const float* dgeom, const float* opacities, const float* raw_rotation,
+    const uint8_t* stable_mask, float* global_scores, float* local_scores, float* kf_max_scores,
+    int64_t* kf_id, int64_t this_kf, int bookkeeping, float* g_xyz, float* g_rgb, float* g_opacity,
+    float* g_scaling, float* g_rotation, uint8_t* visible, float* scores_grad, void* stream);
+
 /* ------------------------------------------------------------------------
  * Forward-only importance of every splat in one view: importance[i] (+)= sum over pixels of
  * the blend weight alpha*T, i.e. the value the backward pass leaves in scores.grad[:,0]

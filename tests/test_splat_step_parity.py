@@ -149,3 +149,65 @@ def test_fused_view_matches_autograd_view():
     close(a.global_scores, b.global_scores, "global_scores", tol=1e-4)
     close(a.local_scores, b.local_scores, "local_scores", tol=1e-4)
     close(a.globalkf_max_scores, b.globalkf_max_scores, "kf_max", tol=1e-4)
+
+
+@pytest.mark.parametrize("bookkeeping", [1, 0])
+def test_project_backward_finish_equals_the_two_calls(bookkeeping):
+    """vings_surfel_project_backward_finish against vings_surfel_project_backward followed by
+    vings_splat_grad_finish on the same blend-pass output: every output bit-identical."""
+    from vings_mono_amd import surfel
+    dev = torch.device(DEV)
+    L = _lib.lib()
+    p = _lib.ptr
+    W, H, n = 160, 96, 4000
+    raw = {k: v.to(dev) for k, v in synth.make_splats(n, W, H, n_views=2, seed=7).items()}
+    intr = synth.intrinsic_for(W, H)
+    w2c = torch.linalg.inv(synth.window_poses(2)[1]).to(dev)
+    act = synth.activate(raw)
+    opac, scales, rot = (act[k].contiguous() for k in ("opacities", "scales", "rotations"))
+    xyz, rgb = raw["_xyz"].contiguous(), raw["_rgb"].contiguous()
+    st, aux = surfel.rasterize_forward(xyz, rgb, opac, scales, rot, harness.view_settings(w2c, intr))
+    g = torch.Generator(device="cpu").manual_seed(3)
+    g_color = torch.randn(3, H, W, generator=g).to(dev)
+    g_allmap = torch.randn(surfel.AUX_CHANNELS, H, W, generator=g).to(dev)
+    dgeom = surfel.blend_backward(st, aux, g_color, g_allmap)
+    stable = (torch.arange(n, device=dev) % 5 == 0).to(torch.uint8)
+    stream = _lib.stream_ptr(dev)
+
+    def records():
+        gen = torch.Generator(device="cpu").manual_seed(11)
+        return [torch.rand(n, 2, generator=gen).to(dev) * 3, torch.rand(n, 2, generator=gen).to(dev),
+                torch.rand(n, generator=gen).to(dev) * 0.05, torch.zeros(n, dtype=torch.int64, device=dev)]
+
+    def outputs():
+        return [torch.full((n, w), 7.0, device=dev) for w in (3, 3, 1, 2, 4)] + \
+               [torch.full((n,), 9, dtype=torch.uint8, device=dev)]
+
+    # two calls
+    d = [torch.empty((n, w), device=dev) for w in (3, 2, 4, 1, 3)]     # xyz, scales, rot, opac, colour
+    cur = torch.empty((n, 2), device=dev)
+    _lib.check(L.vings_surfel_project_backward(
+        n, H, W, 1.0, p(xyz), p(scales), p(rot), p(aux[0]), p(aux[1]), p(st.radii), p(dgeom),
+        p(d[0]), p(d[1]), p(d[2]), p(d[3]), p(d[4]), None, p(cur), stream), "project_backward")
+    rec_a, out_a = records(), outputs()
+    _lib.check(L.vings_splat_grad_finish(
+        n, p(opac), p(scales), p(raw["_rotation"]), p(d[0]), p(d[4]), p(d[3]), p(d[1]), p(d[2]),
+        p(cur), p(st.radii), p(stable), p(rec_a[0]), p(rec_a[1]), p(rec_a[2]), p(rec_a[3]), 5,
+        bookkeeping, *[p(t) for t in out_a], stream), "grad_finish")
+    # one call
+    rec_b, out_b = records(), outputs()
+    cur_b = torch.empty((n, 2), device=dev)
+    _lib.check(L.vings_surfel_project_backward_finish(
+        n, H, W, 1.0, p(xyz), p(scales), p(rot), p(aux[0]), p(aux[1]), p(st.radii), p(dgeom),
+        p(opac), p(raw["_rotation"]), p(stable), p(rec_b[0]), p(rec_b[1]), p(rec_b[2]), p(rec_b[3]),
+        5, bookkeeping, *[p(t) for t in out_b], p(cur_b), stream), "project_backward_finish")
+    torch.cuda.synchronize()
+    assert float(out_a[0].abs().max()) > 0 and int(out_a[5].sum()) > 0
+    for x, y in zip(out_a + rec_a + [cur], out_b + rec_b + [cur_b]):
+        assert torch.equal(x, y)
+    # scores_grad is optional
+    _lib.check(L.vings_surfel_project_backward_finish(
+        n, H, W, 1.0, p(xyz), p(scales), p(rot), p(aux[0]), p(aux[1]), p(st.radii), p(dgeom),
+        p(opac), p(raw["_rotation"]), None, p(rec_b[0]), p(rec_b[1]), p(rec_b[2]), p(rec_b[3]),
+        6, 0, *[p(t) for t in out_b], None, stream), "project_backward_finish")
+    torch.cuda.synchronize()

@@ -1,0 +1,71 @@
+// Chain rule through the parameter activations, score-weighted gradient scaling, score
+// bookkeeping and the optimiser's visibility flag for ONE splat, shared by the stand-alone
+// kernel (splat_step.hip) and the one fused behind the rasteriser's per-splat backward
+// (surfel_project.hip).  Same float32 expression order in both, so they agree bit for bit.
+//   add_records (score update)    /root/reference/scripts/gaussian/gaussian_model.py:163-168
+//   weighting_grad                /root/reference/scripts/gaussian/gaussian_utils.py:56-62
+//   visibility for the optimiser  /root/reference/scripts/gaussian/gaussian_base.py:385-402
+#pragma once
+#include "common.hpp"
+
+namespace vings {
+
+struct FinishArgs {
+    const float* opacities; const float* scales; const float* raw_rotation;   // forward values
+    const float* d_means3D; const float* d_colors; const float* d_opacities;  // w.r.t. activated
+    const float* d_scales; const float* d_rotations;
+    const float* cur_scores;      // [N,2] scores.grad of this view
+    const int* radii; const uint8_t* stable_mask;
+    float* global_scores; float* local_scores;   // [N,2]
+    float* kf_max_scores; int64_t* kf_id;        // [N]
+    float* g_xyz; float* g_rgb; float* g_opacity; float* g_scaling; float* g_rotation;
+    uint8_t* visible;
+    int64_t this_kf;
+    int bookkeeping;
+};
+
+// dm / dc / dop / ds / g: gradients w.r.t. the position, colour and the ACTIVATED opacity,
+// scales and rotation of splat i; s0 / s1: the view's importance and error score.
+__device__ __forceinline__ void splat_finish(int i, const FinishArgs& a, const float dm[3],
+                                             const float dc[3], float dop, float2 ds, float4 g,
+                                             float s0, float s1) {
+    const float g0_old = a.global_scores[2 * i];
+    const float g0_new = fminf(fmaxf(g0_old + s0, 0.0f), 1e4f);
+    // gradient weight: this view's share of the splat's accumulated importance
+    const float w = s0 / (g0_new + 1e-6f + s0);
+    if (a.bookkeeping) {
+        a.global_scores[2 * i] = g0_new;
+        a.local_scores[2 * i] += s0;
+        a.local_scores[2 * i + 1] = fmaxf(a.local_scores[2 * i + 1], s1);
+        if (a.kf_max_scores[i] < s0) { a.kf_max_scores[i] = s0; a.kf_id[i] = a.this_kf; }
+    }
+    const bool stable = a.stable_mask && a.stable_mask[i];
+    a.visible[i] = (a.radii[i] > 0 && !stable) ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        a.g_xyz[3 * i + k] = dm[k] * w;
+        a.g_rgb[3 * i + k] = dc[k] * w;
+    }
+    const float o = a.opacities[i];
+    a.g_opacity[i] = dop * (o * (1.0f - o)) * w;          // sigmoid'
+    const float2 s = reinterpret_cast<const float2*>(a.scales)[i];
+    reinterpret_cast<float2*>(a.g_scaling)[i] = make_float2(ds.x * s.x * w, ds.y * s.y * w);  // exp'
+    // x / max(|x|, eps): d/dx = (g - n (n.g)) / |x|
+    const float4 q = reinterpret_cast<const float4*>(a.raw_rotation)[i];
+    const float len = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    float4 out;
+    if (len > 1e-12f) {
+        const float inv = 1.0f / len;
+        const float nx = q.x * inv, ny = q.y * inv, nz = q.z * inv, nw = q.w * inv;
+        const float ng = nx * g.x + ny * g.y + nz * g.z + nw * g.w;
+        const float k = inv * w;
+        out = make_float4((g.x - nx * ng) * k, (g.y - ny * ng) * k, (g.z - nz * ng) * k,
+                          (g.w - nw * ng) * k);
+    } else {
+        const float k = 1e12f * w;
+        out = make_float4(g.x * k, g.y * k, g.z * k, g.w * k);
+    }
+    reinterpret_cast<float4*>(a.g_rotation)[i] = out;
+}
+
+}  // namespace vings

@@ -11,6 +11,7 @@
 #include <mutex>
 
 #include "common.hpp"
+#include "splat_finish.hpp"
 
 namespace vings {
 
@@ -260,19 +261,20 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(uint32_t* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void project_bwd_kernel(
-    int N, int H, int W, float scale_mod, const float* __restrict__ means3D,
+// Gradients of one splat w.r.t. its position, activated scales / rotation / opacity, colour,
+// its 2-D mean and the two score inputs, from the blend pass's per-splat accumulator row.
+struct SplatGrad {
+    float dm[3], ds[2], dq[4], dop, dc[3], dxy[2], sc[2];
+};
+
+__device__ __forceinline__ void splat_backward(
+    int i, int H, int W, float scale_mod, const float* __restrict__ means3D,
     const float* __restrict__ scales, const float* __restrict__ rots,
-    const float* __restrict__ view, const float* __restrict__ proj,
-    const int32_t* __restrict__ radii, const float* __restrict__ dgeom,
-    float* __restrict__ d_means3D, float* __restrict__ d_scales, float* __restrict__ d_rots,
-    float* __restrict__ d_opac, float* __restrict__ d_colors, float* __restrict__ d_means2D,
-    float* __restrict__ scores) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
+    const float* __restrict__ view, const float* __restrict__ proj, int radii_i,
+    const float* __restrict__ dgeom, SplatGrad& o) {
     float dm[3] = {0, 0, 0}, ds[2] = {0, 0}, dq[4] = {0, 0, 0, 0};
     float dop = 0, dc[3] = {0, 0, 0}, dxy[2] = {0, 0}, sc[2] = {0, 0};
-    if (radii[i] > 0) {
+    if (radii_i > 0) {
         const float4* g4 = reinterpret_cast<const float4*>(dgeom + (size_t)i * VINGS_GRAD_STRIDE);
         const float4 g0 = g4[0], g1 = g4[1], g2 = g4[2], g3 = g4[3], g4v = g4[4];
         float dA[3][3] = {{g0.x, g0.y, g0.z}, {g0.w, g1.x, g1.y}, {g1.z, g1.w, g2.x}};
@@ -334,15 +336,52 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
         dq[3] = 2 * (-2 * z * g[0][0] - r * g[0][1] + x * g[0][2] + r * g[1][0] - 2 * z * g[1][1] +
                      y * g[1][2] + x * g[2][0] + y * g[2][1]);
     }
-    d_means3D[3 * i] = dm[0]; d_means3D[3 * i + 1] = dm[1]; d_means3D[3 * i + 2] = dm[2];
-    reinterpret_cast<float2*>(d_scales)[i] = make_float2(ds[0], ds[1]);
-    reinterpret_cast<float4*>(d_rots)[i] = make_float4(dq[0], dq[1], dq[2], dq[3]);
-    d_opac[i] = dop;
-    d_colors[3 * i] = dc[0]; d_colors[3 * i + 1] = dc[1]; d_colors[3 * i + 2] = dc[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o.dm[k] = dm[k]; o.dc[k] = dc[k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o.dq[k] = dq[k];
+    o.ds[0] = ds[0]; o.ds[1] = ds[1]; o.dop = dop;
+    o.dxy[0] = dxy[0]; o.dxy[1] = dxy[1]; o.sc[0] = sc[0]; o.sc[1] = sc[1];
+}
+
+__global__ __launch_bounds__(256) void project_bwd_kernel(
+    int N, int H, int W, float scale_mod, const float* __restrict__ means3D,
+    const float* __restrict__ scales, const float* __restrict__ rots,
+    const float* __restrict__ view, const float* __restrict__ proj,
+    const int32_t* __restrict__ radii, const float* __restrict__ dgeom,
+    float* __restrict__ d_means3D, float* __restrict__ d_scales, float* __restrict__ d_rots,
+    float* __restrict__ d_opac, float* __restrict__ d_colors, float* __restrict__ d_means2D,
+    float* __restrict__ scores) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    SplatGrad g;
+    splat_backward(i, H, W, scale_mod, means3D, scales, rots, view, proj, radii[i], dgeom, g);
+    d_means3D[3 * i] = g.dm[0]; d_means3D[3 * i + 1] = g.dm[1]; d_means3D[3 * i + 2] = g.dm[2];
+    reinterpret_cast<float2*>(d_scales)[i] = make_float2(g.ds[0], g.ds[1]);
+    reinterpret_cast<float4*>(d_rots)[i] = make_float4(g.dq[0], g.dq[1], g.dq[2], g.dq[3]);
+    d_opac[i] = g.dop;
+    d_colors[3 * i] = g.dc[0]; d_colors[3 * i + 1] = g.dc[1]; d_colors[3 * i + 2] = g.dc[2];
     if (d_means2D) {
-        d_means2D[3 * i] = dxy[0]; d_means2D[3 * i + 1] = dxy[1]; d_means2D[3 * i + 2] = 0.f;
+        d_means2D[3 * i] = g.dxy[0]; d_means2D[3 * i + 1] = g.dxy[1]; d_means2D[3 * i + 2] = 0.f;
     }
-    if (scores) reinterpret_cast<float2*>(scores)[i] = make_float2(sc[0], sc[1]);
+    if (scores) reinterpret_cast<float2*>(scores)[i] = make_float2(g.sc[0], g.sc[1]);
+}
+
+// The same per-splat backward with the mapper's chain rule, score weighting and bookkeeping
+// (splat_finish) applied in registers: the seven gradient arrays w.r.t. the activated
+// parameters never reach memory.  `scores` (optional) still receives the view's two scores.
+__global__ __launch_bounds__(256) void project_bwd_finish_kernel(
+    int N, int H, int W, float scale_mod, const float* __restrict__ means3D,
+    const float* __restrict__ rots, const float* __restrict__ view,
+    const float* __restrict__ proj, const float* __restrict__ dgeom, FinishArgs a,
+    float* __restrict__ scores) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    SplatGrad g;
+    splat_backward(i, H, W, scale_mod, means3D, a.scales, rots, view, proj, a.radii[i], dgeom, g);
+    if (scores) reinterpret_cast<float2*>(scores)[i] = make_float2(g.sc[0], g.sc[1]);
+    splat_finish(i, a, g.dm, g.dc, g.dop, make_float2(g.ds[0], g.ds[1]),
+                 make_float4(g.dq[0], g.dq[1], g.dq[2], g.dq[3]), g.sc[0], g.sc[1]);
 }
 
 // One 64-byte pinned, device-visible host buffer per GPU, created at the first projection call
@@ -475,6 +514,40 @@ extern "C" int vings_surfel_project_backward(int N, int H, int W, float scale_mo
         N, H, W, scale_modifier, means3D, scales, rotations, viewmatrix, projmatrix, radii, dgeom,
         dL_dmeans3D, dL_dscales, dL_drotations, dL_dopacities, dL_dcolors, dL_dmeans2D,
         scores_grad);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}
+
+extern "C" int vings_surfel_project_backward_finish(
+    int N, int H, int W, float scale_modifier, const float* means3D, const float* scales,
+    const float* rotations, const float* viewmatrix, const float* projmatrix, const int32_t* radii,
+    const float* dgeom, const float* opacities, const float* raw_rotation,
+    const uint8_t* stable_mask, float* global_scores, float* local_scores, float* kf_max_scores,
+    int64_t* kf_id, int64_t this_kf, int bookkeeping, float* g_xyz, float* g_rgb, float* g_opacity,
+    float* g_scaling, float* g_rotation, uint8_t* visible, float* scores_grad, void* stream) {
+    VINGS_REQUIRE(N >= 0 && H > 0 && W > 0, "sizes");
+    if (N == 0) return VINGS_OK;
+    VINGS_REQUIRE(means3D && scales && rotations && viewmatrix && projmatrix && radii && dgeom &&
+                      opacities && raw_rotation && global_scores,
+                  "null input");
+    VINGS_REQUIRE(g_xyz && g_rgb && g_opacity && g_scaling && g_rotation && visible, "null output");
+    VINGS_REQUIRE(!bookkeeping || (local_scores && kf_max_scores && kf_id),
+                  "bookkeeping needs the score arrays");
+    VINGS_REQUIRE((((uintptr_t)raw_rotation | (uintptr_t)rotations | (uintptr_t)g_rotation |
+                    (uintptr_t)dgeom) & 15) == 0 &&
+                      (((uintptr_t)scales | (uintptr_t)g_scaling | (uintptr_t)scores_grad) & 7) == 0,
+                  "rotation arrays / dgeom must be 16-byte aligned, scaling / score arrays 8-byte aligned");
+    FinishArgs a = {};
+    a.opacities = opacities; a.scales = scales; a.raw_rotation = raw_rotation;
+    a.radii = radii; a.stable_mask = stable_mask; a.global_scores = global_scores;
+    a.local_scores = local_scores; a.kf_max_scores = kf_max_scores; a.kf_id = kf_id;
+    a.g_xyz = g_xyz; a.g_rgb = g_rgb; a.g_opacity = g_opacity; a.g_scaling = g_scaling;
+    a.g_rotation = g_rotation; a.visible = visible; a.this_kf = this_kf;
+    a.bookkeeping = bookkeeping;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(PROF_PROJECT_BWD, s);
+    project_bwd_finish_kernel<<<cdiv(N, 256), 256, 0, s>>>(
+        N, H, W, scale_modifier, means3D, rotations, viewmatrix, projmatrix, dgeom, a, scores_grad);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }

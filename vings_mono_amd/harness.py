@@ -306,6 +306,7 @@ class SurfelMapper:
             n, dev = self.n, self.device
             e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)
             fb = {"opac": e(n, 1), "scales": e(n, 2), "rot": e(n, 4), "vis": e(n, dt=torch.uint8),
+                  "cur": e(n, 2),
                   "grads": {k: torch.zeros_like(self.params[k]) for k in self.NAMES}}
             for k in self.NAMES:
                 self.params[k].grad = fb["grads"][k]   # the optimiser reads .grad
@@ -331,18 +332,22 @@ class SurfelMapper:
             st, aux = surfel.rasterize_forward(xyz, rgb, fb["opac"], fb["scales"], fb["rot"], settings)
             loss_vec, d_rgb, d_allmap = mapping_loss_hip(st.color, st.allmap, gt, Rw2c_host, intr,
                                                          self.loss_weights)
-            d_xyz, _, d_col, d_opac, d_scales, d_rot, cur = surfel.rasterize_backward(
-                st, aux, xyz, fb["scales"], fb["rot"], 1.0, d_rgb, d_allmap, want_means2D=False)
             single = reducer is None or reducer.world == 1
             g = fb["grads"]
-            _lib.check(L.vings_splat_grad_finish(
-                n, ptr(fb["opac"]), ptr(fb["scales"]), ptr(P["_rotation"]), ptr(d_xyz), ptr(d_col),
-                ptr(d_opac), ptr(d_scales), ptr(d_rot), ptr(cur), ptr(st.radii),
+            cur = fb["cur"]
+            view, proj = aux[0], aux[1]
+            dgeom = surfel.blend_backward(st, aux, d_rgb, d_allmap)
+            # per-splat backward + chain rule through the activations + score weighting +
+            # bookkeeping in one launch
+            _lib.check(L.vings_surfel_project_backward_finish(
+                n, st.H, st.W, 1.0, ptr(xyz), ptr(fb["scales"]), ptr(fb["rot"]), ptr(view),
+                ptr(proj), ptr(st.radii), ptr(dgeom), ptr(fb["opac"]), ptr(P["_rotation"]),
                 ptr(self.stable_mask.view(torch.uint8)), ptr(self.global_scores),
                 ptr(self.local_scores), ptr(self.globalkf_max_scores), ptr(self.globalkf_id),
                 int(kf_id), 1 if single else 0, ptr(g["_xyz"]), ptr(g["_rgb"]), ptr(g["_opacity"]),
-                ptr(g["_scaling"]), ptr(g["_rotation"]), ptr(fb["vis"]), stream),
-                "vings_splat_grad_finish")
+                ptr(g["_scaling"]), ptr(g["_rotation"]), ptr(fb["vis"]),
+                None if single else ptr(cur), stream),
+                "vings_surfel_project_backward_finish")
             vis = fb["vis"]
             if not single:
                 # pack -> SUM all-reduce over the replicas -> unpack + score sums

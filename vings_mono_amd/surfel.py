@@ -187,6 +187,21 @@ def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys,
     return st, aux
 
 
+def blend_backward(st, aux, g_color, g_allmap):
+    """Pixel half of the backward pass: the per-splat accumulator rows dgeom [N, GRAD_STRIDE]
+    that vings_surfel_project_backward (or its fused _finish form) turns into gradients."""
+    L = _lib.lib()
+    _, _, bg, mask, _ = aux
+    N, H, W = st.N, st.H, st.W
+    dev = st.geom.device
+    dgeom = torch.empty((max(N, 1), GRAD_STRIDE), dtype=torch.float32, device=dev)
+    check(L.vings_surfel_blend_backward(
+        N, H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg), ptr(mask), ptr(st.final_T),
+        ptr(st.n_contrib), ptr(g_color), ptr(g_allmap), ptr(dgeom), stream_ptr(dev)),
+        "vings_surfel_blend_backward")
+    return dgeom
+
+
 def rasterize_backward(st, aux, means3D, scales, rotations, scale_modifier, g_color, g_allmap,
                        want_means2D=True, want_scores=True):
     L = _lib.lib()
@@ -194,11 +209,7 @@ def rasterize_backward(st, aux, means3D, scales, rotations, scale_modifier, g_co
     view, proj, bg, mask, _ = aux
     N, H, W = st.N, st.H, st.W
     stream = stream_ptr(dev)
-    dgeom = torch.empty((max(N, 1), GRAD_STRIDE), dtype=torch.float32, device=dev)
-    check(L.vings_surfel_blend_backward(
-        N, H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg), ptr(mask), ptr(st.final_T),
-        ptr(st.n_contrib), ptr(g_color), ptr(g_allmap), ptr(dgeom), stream),
-        "vings_surfel_blend_backward")
+    dgeom = blend_backward(st, aux, g_color, g_allmap)
     d_means3D = torch.empty((N, 3), dtype=torch.float32, device=dev)
     d_scales = torch.empty((N, 2), dtype=torch.float32, device=dev)
     d_rot = torch.empty((N, 4), dtype=torch.float32, device=dev)
