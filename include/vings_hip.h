@@ -95,6 +95,17 @@ int vings_surfel_project_launch(int N, int H, int W, float scale_modifier,
                                 const float* viewmatrix, const float* projmatrix,
                                 float* geom, float* depth, int32_t* radii, int32_t* rect,
                                 uint32_t* tiles_touched, uint32_t* block_prefix, void* stream);
+/* vings_surfel_project_launch on the STORED parameters: the kernel applies the mapper's
+ * activations itself (scales = exp(raw_scaling), rotations = raw_rotation / max(|.|, 1e-12),
+ * opacities = sigmoid(raw_opacity): gaussian_base.py:44-48,64-72; bit-identical to
+ * vings_splat_activate) and leaves the activated arrays in scales / rotations / opacities for
+ * the backward pass.  Saves the separate activation launch of the mapper's view step. */
+int vings_surfel_project_launch_activate(
+    int N, int H, int W, float scale_modifier, const float* means3D, const float* raw_scaling,
+    const float* raw_rotation, const float* raw_opacity, const float* colors, const float* flow,
+    const float* viewmatrix, const float* projmatrix, float* scales, float* rotations,
+    float* opacities, float* geom, float* depth, int32_t* radii, int32_t* rect,
+    uint32_t* tiles_touched, uint32_t* block_prefix, void* stream);
 int vings_surfel_project_wait(int64_t* num_instances_host, uint32_t* depth_bits_range_host);
 
 /* Bytes of scratch vings_surfel_bin needs for D instances. */

@@ -211,3 +211,37 @@ def test_project_backward_finish_equals_the_two_calls(bookkeeping):
         p(opac), p(raw["_rotation"]), None, p(rec_b[0]), p(rec_b[1]), p(rec_b[2]), p(rec_b[3]),
         6, 0, *[p(t) for t in out_b], None, stream), "project_backward_finish")
     torch.cuda.synchronize()
+
+
+def test_projection_with_inline_activation_equals_activate_then_project():
+    """rasterize_forward(raw=...) (activations applied inside the projection kernel) against
+    vings_splat_activate followed by the plain forward pass: activated arrays and every
+    forward output bit-identical, on the first (exact) and the second (speculative) launch."""
+    from vings_mono_amd import surfel
+    dev = torch.device(DEV)
+    L = _lib.lib()
+    p = _lib.ptr
+    W, H, n = 176, 112, 6000
+    raw = {k: v.to(dev).contiguous() for k, v in synth.make_splats(n, W, H, n_views=2, seed=9).items()}
+    raw["_rotation"][5] = 0.0                                  # degenerate quaternion
+    intr = synth.intrinsic_for(W, H)
+    settings = harness.view_settings(torch.linalg.inv(synth.window_poses(2)[1]).to(dev), intr)
+    e = lambda *s: torch.empty(*s, device=dev)
+    o1, s1, r1 = e(n, 1), e(n, 2), e(n, 4)
+    _lib.check(L.vings_splat_activate(n, p(raw["_opacity"]), p(raw["_scaling"]), p(raw["_rotation"]),
+                                      p(o1), p(s1), p(r1), _lib.stream_ptr(dev)), "activate")
+    want = surfel.rasterize_forward(raw["_xyz"], raw["_rgb"], o1, s1, r1, settings, keep_keys=True)[0]
+    surfel._D_HINT.clear()
+    for _ in range(2):
+        o2, s2, r2 = (torch.full_like(t, 5.0) for t in (o1, s1, r1))
+        got = surfel.rasterize_forward(raw["_xyz"], raw["_rgb"], o2, s2, r2, settings, keep_keys=True,
+                                       raw=(raw["_opacity"], raw["_scaling"], raw["_rotation"]))[0]
+        assert torch.equal(o1, o2) and torch.equal(s1, s2) and torch.equal(r1, r2)
+        assert got.D == want.D and want.D > 0
+        for name in ("geom", "depth", "rect", "ranges", "radii", "n_contrib", "color", "allmap", "final_T"):
+            a, b = getattr(want, name), getattr(got, name)
+            if name == "geom":                                  # rows of culled splats are not written
+                vis = want.radii > 0
+                a, b = a[vis], b[vis]
+            assert torch.equal(a, b), name
+        assert torch.equal(want.keys[:want.D], got.keys[:got.D])

@@ -57,18 +57,15 @@ struct SplatFrame {
     float sx, sy, mult;
 };
 
-__device__ __forceinline__ void splat_frame(const float* __restrict__ means3D,
-                                            const float* __restrict__ scales,
-                                            const float* __restrict__ rots,
-                                            const float* __restrict__ view, const PixProj& B,
-                                            float scale_mod, int i, SplatFrame& f) {
+__device__ __forceinline__ void splat_frame_of(const float* __restrict__ means3D, float2 s,
+                                               float4 q, const float* __restrict__ view,
+                                               const PixProj& B, float scale_mod, int i,
+                                               SplatFrame& f) {
     const float p0 = means3D[3 * i], p1 = means3D[3 * i + 1], p2 = means3D[3 * i + 2];
     f.pv[0] = view[0] * p0 + view[4] * p1 + view[8] * p2 + view[12];
     f.pv[1] = view[1] * p0 + view[5] * p1 + view[9] * p2 + view[13];
     f.pv[2] = view[2] * p0 + view[6] * p1 + view[10] * p2 + view[14];
-    const float4 q = reinterpret_cast<const float4*>(rots)[i];
     quat_to_R(q, f.R);
-    const float2 s = reinterpret_cast<const float2*>(scales)[i];
     f.sx = scale_mod * s.x;
     f.sy = scale_mod * s.y;
     const float L0[3] = {f.R[0][0] * f.sx, f.R[1][0] * f.sx, f.R[2][0] * f.sx};
@@ -87,10 +84,24 @@ __device__ __forceinline__ void splat_frame(const float* __restrict__ means3D,
     f.mult = cosv == 0.f ? 0.f : (cosv > 0.f ? 1.f : -1.f);
 }
 
+__device__ __forceinline__ void splat_frame(const float* __restrict__ means3D,
+                                            const float* __restrict__ scales,
+                                            const float* __restrict__ rots,
+                                            const float* __restrict__ view, const PixProj& B,
+                                            float scale_mod, int i, SplatFrame& f) {
+    splat_frame_of(means3D, reinterpret_cast<const float2*>(scales)[i],
+                   reinterpret_cast<const float4*>(rots)[i], view, B, scale_mod, i, f);
+}
+
+// kRaw: scales / rots / opac hold the STORED parameters; the kernel applies the mapper's
+// activations (exp, normalise, sigmoid: gaussian_base.py:44-48,64-72, the expressions of
+// splat_activate_kernel) itself and leaves the activated values in act_* for the backward pass.
+template <bool kRaw>
 __global__ __launch_bounds__(256) void project_fwd_kernel(
     int N, int H, int W, float scale_mod, const float* __restrict__ means3D,
     const float* __restrict__ scales, const float* __restrict__ rots,
-    const float* __restrict__ opac, const float* __restrict__ colors,
+    const float* __restrict__ opac, float* __restrict__ act_scales, float* __restrict__ act_rots,
+    float* __restrict__ act_opac, const float* __restrict__ colors,
     const float* __restrict__ flow, const float* __restrict__ view,
     const float* __restrict__ proj, float* __restrict__ geom, float* __restrict__ depth,
     int32_t* __restrict__ radii, int32_t* __restrict__ rect, uint32_t* __restrict__ tiles_touched,
@@ -107,7 +118,19 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
         float dep = 0.f;
         const PixProj B = pixel_projection(proj, W, H);
         SplatFrame f;
-        splat_frame(means3D, scales, rots, view, B, scale_mod, i, f);
+        float2 s2 = reinterpret_cast<const float2*>(scales)[i];
+        float4 q4 = reinterpret_cast<const float4*>(rots)[i];
+        float o = opac[i];
+        if (kRaw) {
+            o = 1.0f / (1.0f + expf(-o));
+            s2 = make_float2(expf(s2.x), expf(s2.y));
+            const float inv = 1.0f / fmaxf(sqrtf(q4.x * q4.x + q4.y * q4.y + q4.z * q4.z + q4.w * q4.w), 1e-12f);
+            q4 = make_float4(q4.x * inv, q4.y * inv, q4.z * inv, q4.w * inv);
+            act_opac[i] = o;
+            reinterpret_cast<float2*>(act_scales)[i] = s2;
+            reinterpret_cast<float4*>(act_rots)[i] = q4;
+        }
+        splat_frame_of(means3D, s2, q4, view, B, scale_mod, i, f);
         bool ok = f.pv[2] > kNear && f.mult != 0.f;
         float cx = 0.f, cy = 0.f;
         if (ok) {
@@ -152,7 +175,6 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
         reinterpret_cast<int4*>(rect)[i] = make_int4(x0, y0, x1, y1);
         if (ok) {
             float4* g = reinterpret_cast<float4*>(geom + (size_t)i * VINGS_GEOM_STRIDE);
-            const float o = opac[i];
             const float c0 = colors[3 * i], c1 = colors[3 * i + 1], c2 = colors[3 * i + 2];
             float fl0 = 0.f, fl1 = 0.f;
             if (flow) { fl0 = flow[2 * i]; fl1 = flow[2 * i + 1]; }
@@ -405,7 +427,8 @@ static int project_launch(int N, int H, int W, float scale_modifier, const float
                           const float* colors, const float* flow, const float* viewmatrix,
                           const float* projmatrix, float* geom, float* depth, int32_t* radii,
                           int32_t* rect, uint32_t* tiles_touched, uint32_t* block_prefix,
-                          hipStream_t s, int* dev_out) {
+                          hipStream_t s, int* dev_out, float* act_scales = nullptr,
+                          float* act_rotations = nullptr, float* act_opacities = nullptr) {
     VINGS_REQUIRE(N > 0 && H > 0 && W > 0, "sizes");
     VINGS_REQUIRE(means3D && scales && rotations && opacities && colors && viewmatrix &&
                       projmatrix && geom && depth && radii && rect && tiles_touched && block_prefix,
@@ -420,10 +443,16 @@ static int project_launch(int N, int H, int W, float scale_modifier, const float
     const int nb = cdiv(N, 256);
     {
     ProfScope prof(PROF_PROJECT_FWD, s);
-    project_fwd_kernel<<<nb, 256, 0, s>>>(N, H, W, scale_modifier, means3D, scales, rotations,
-                                          opacities, colors, flow, viewmatrix, projmatrix, geom,
-                                          depth, radii, rect, tiles_touched, block_prefix,
-                                          block_prefix + nb + 1, block_prefix + 2 * nb + 1);
+    if (act_scales)
+        project_fwd_kernel<true><<<nb, 256, 0, s>>>(
+            N, H, W, scale_modifier, means3D, scales, rotations, opacities, act_scales,
+            act_rotations, act_opacities, colors, flow, viewmatrix, projmatrix, geom, depth, radii,
+            rect, tiles_touched, block_prefix, block_prefix + nb + 1, block_prefix + 2 * nb + 1);
+    else
+        project_fwd_kernel<false><<<nb, 256, 0, s>>>(
+            N, H, W, scale_modifier, means3D, scales, rotations, opacities, nullptr, nullptr,
+            nullptr, colors, flow, viewmatrix, projmatrix, geom, depth, radii, rect, tiles_touched,
+            block_prefix, block_prefix + nb + 1, block_prefix + 2 * nb + 1);
     VINGS_LAUNCH_CHECK();
     }
     scan_blocks_kernel<<<1, 1024, 0, s>>>(block_prefix, nb, g_mail[dev]);
@@ -483,6 +512,23 @@ extern "C" int vings_surfel_project_launch(int N, int H, int W, float scale_modi
     return project_launch(N, H, W, scale_modifier, means3D, scales, rotations, opacities, colors,
                           flow, viewmatrix, projmatrix, geom, depth, radii, rect, tiles_touched,
                           block_prefix, (hipStream_t)stream, &dev);
+}
+
+extern "C" int vings_surfel_project_launch_activate(
+    int N, int H, int W, float scale_modifier, const float* means3D, const float* raw_scaling,
+    const float* raw_rotation, const float* raw_opacity, const float* colors, const float* flow,
+    const float* viewmatrix, const float* projmatrix, float* scales, float* rotations,
+    float* opacities, float* geom, float* depth, int32_t* radii, int32_t* rect,
+    uint32_t* tiles_touched, uint32_t* block_prefix, void* stream) {
+    VINGS_REQUIRE(scales && rotations && opacities, "null pointer");
+    VINGS_REQUIRE((((uintptr_t)rotations | (uintptr_t)raw_rotation) & 15) == 0 &&
+                      (((uintptr_t)scales | (uintptr_t)raw_scaling) & 7) == 0,
+                  "rotation arrays must be 16-byte aligned, scaling arrays 8-byte aligned");
+    int dev = 0;
+    return project_launch(N, H, W, scale_modifier, means3D, raw_scaling, raw_rotation, raw_opacity,
+                          colors, flow, viewmatrix, projmatrix, geom, depth, radii, rect,
+                          tiles_touched, block_prefix, (hipStream_t)stream, &dev, scales, rotations,
+                          opacities);
 }
 
 extern "C" int vings_surfel_project_wait(int64_t* num_instances_host,

@@ -325,11 +325,11 @@ class SurfelMapper:
         stream = _lib.stream_ptr(dev)
         ptr = _lib.ptr
         with torch.no_grad():
-            _lib.check(L.vings_splat_activate(n, ptr(P["_opacity"]), ptr(P["_scaling"]),
-                                              ptr(P["_rotation"]), ptr(fb["opac"]), ptr(fb["scales"]),
-                                              ptr(fb["rot"]), stream), "vings_splat_activate")
+            # the projection applies the activations itself and fills fb["opac" / "scales" / "rot"]
             xyz, rgb = P["_xyz"].detach(), P["_rgb"].detach()
-            st, aux = surfel.rasterize_forward(xyz, rgb, fb["opac"], fb["scales"], fb["rot"], settings)
+            st, aux = surfel.rasterize_forward(
+                xyz, rgb, fb["opac"], fb["scales"], fb["rot"], settings,
+                raw=(P["_opacity"].detach(), P["_scaling"].detach(), P["_rotation"].detach()))
             loss_vec, d_rgb, d_allmap = mapping_loss_hip(st.color, st.allmap, gt, Rw2c_host, intr,
                                                          self.loss_weights)
             single = reducer is None or reducer.world == 1

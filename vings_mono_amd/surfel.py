@@ -56,9 +56,14 @@ class SurfelForwardState:
                  "allmap")
 
 
-def rasterize_forward(means3D, colors, opacities, scales, rotations, settings, keep_keys=False):
-    """Run projection -> binning -> blend. Returns (SurfelForwardState, aux)."""
-    return _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys, True)
+def rasterize_forward(means3D, colors, opacities, scales, rotations, settings, keep_keys=False,
+                      raw=None):
+    """Run projection -> binning -> blend. Returns (SurfelForwardState, aux).
+
+    `raw` = (raw_opacity, raw_scaling, raw_rotation): the stored parameters.  The projection
+    then applies the mapper's activations itself and FILLS opacities / scales / rotations
+    (which only need to be allocated) instead of reading them."""
+    return _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys, True, raw)
 
 
 def view_importance(means3D, colors, opacities, scales, rotations, settings, out=None,
@@ -85,7 +90,7 @@ SPECULATE = os.environ.get("VINGS_SPECULATE", "1") != "0"   # launch sort + blen
 _D_HINT = {}       # (device index, H, W) -> (instance count, depth key bits) of the latest view
 
 
-def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys, blend):
+def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys, blend, raw=None):
     L = _lib.lib()
     dev = means3D.device
     N = means3D.shape[0]
@@ -124,6 +129,17 @@ def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys,
     d_host = ctypes.c_int64(0)
     d_range = (ctypes.c_uint32 * 2)(0, 0xFFFFFFFF)
 
+    def launch_projection():
+        if raw is None:
+            check(L.vings_surfel_project_launch(*project_args, stream), "vings_surfel_project_launch")
+        else:
+            raw_o, raw_s, raw_r = raw
+            check(L.vings_surfel_project_launch_activate(
+                N, H, W, float(settings.scale_modifier), ptr(means3D), ptr(raw_s), ptr(raw_r),
+                ptr(raw_o), ptr(colors), ptr(flow), ptr(view), ptr(proj), ptr(scales),
+                ptr(rotations), ptr(opacities), *project_args[12:], stream),
+                "vings_surfel_project_launch_activate")
+
     def blend_forward():
         st.color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         st.allmap = torch.empty((AUX_CHANNELS, H, W), dtype=torch.float32, device=dev)
@@ -148,7 +164,7 @@ def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys,
         st.keys = torch.empty(cap, dtype=torch.int64, device=dev)
         st.vals = torch.empty(cap, dtype=torch.int32, device=dev)
         ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
-        check(L.vings_surfel_project_launch(*project_args, stream), "vings_surfel_project_launch")
+        launch_projection()
         tail = st.block_prefix.data_ptr() + 4 * (3 * nb + 1)
         check(L.vings_surfel_bin_speculative(
             N, H, W, cap, hint[1], tail, ptr(st.depth), ptr(st.rect), ptr(st.tiles_touched),
@@ -162,8 +178,12 @@ def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys,
         done = D <= cap and bits <= hint[1]
         _D_HINT[(dev.index, H, W)] = (D, max(bits, hint[1])) if D > 0 else hint
     else:
-        check(L.vings_surfel_project(*project_args, ctypes.byref(d_host), d_range, stream),
-              "vings_surfel_project")
+        if raw is None:
+            check(L.vings_surfel_project(*project_args, ctypes.byref(d_host), d_range, stream),
+                  "vings_surfel_project")
+        elif N > 0:
+            launch_projection()
+            check(L.vings_surfel_project_wait(ctypes.byref(d_host), d_range), "vings_surfel_project_wait")
         D = int(d_host.value)
         if D > 0:
             _D_HINT[(dev.index, H, W)] = (
