@@ -239,14 +239,19 @@ int vings_splat_grad_finish(int N, const float* opacities, const float* scales,
  * parameters stay in registers.  scales / rotations / opacities are the ACTIVATED values the
  * forward pass was given, raw_rotation the stored quaternion; the g_* and visible outputs
  * and the bookkeeping are exactly those of vings_splat_grad_finish (bit-identical).
- * scores_grad [N,2] (optional) receives the view's two scores as the unfused call does. */
+ * scores_grad [N,2] (optional) receives the view's two scores as the unfused call does.
+ * Multi-GPU form: with packed != NULL (then bookkeeping must be 0 and record_keys given) the
+ * weighted gradients, s0 and the visibility flag go straight into the planar exchange buffer
+ * and the record keys are folded into record_keys, exactly as vings_splat_pack_exchange would
+ * do after this call; g_* and visible are then not written and may be NULL. */
 int vings_surfel_project_backward_finish(
     int N, int H, int W, float scale_modifier, const float* means3D, const float* scales,
     const float* rotations, const float* viewmatrix, const float* projmatrix, const int32_t* radii,
     const float* dgeom, const float* opacities, const float* raw_rotation,
     const uint8_t* stable_mask, float* global_scores, float* local_scores, float* kf_max_scores,
     int64_t* kf_id, int64_t this_kf, int bookkeeping, float* g_xyz, float* g_rgb, float* g_opacity,
-    float* g_scaling, float* g_rotation, uint8_t* visible, float* scores_grad, void* stream);
+    float* g_scaling, float* g_rotation, uint8_t* visible, float* scores_grad, float* packed,
+    int64_t* record_keys, void* stream);
 
 /* ------------------------------------------------------------------------
  * Forward-only importance of every splat in one view: importance[i] (+)= sum over pixels of

@@ -200,7 +200,7 @@ def test_project_backward_finish_equals_the_two_calls(bookkeeping):
     _lib.check(L.vings_surfel_project_backward_finish(
         n, H, W, 1.0, p(xyz), p(scales), p(rot), p(aux[0]), p(aux[1]), p(st.radii), p(dgeom),
         p(opac), p(raw["_rotation"]), p(stable), p(rec_b[0]), p(rec_b[1]), p(rec_b[2]), p(rec_b[3]),
-        5, bookkeeping, *[p(t) for t in out_b], p(cur_b), stream), "project_backward_finish")
+        5, bookkeeping, *[p(t) for t in out_b], p(cur_b), None, None, stream), "project_backward_finish")
     torch.cuda.synchronize()
     assert float(out_a[0].abs().max()) > 0 and int(out_a[5].sum()) > 0
     for x, y in zip(out_a + rec_a + [cur], out_b + rec_b + [cur_b]):
@@ -209,8 +209,24 @@ def test_project_backward_finish_equals_the_two_calls(bookkeeping):
     _lib.check(L.vings_surfel_project_backward_finish(
         n, H, W, 1.0, p(xyz), p(scales), p(rot), p(aux[0]), p(aux[1]), p(st.radii), p(dgeom),
         p(opac), p(raw["_rotation"]), None, p(rec_b[0]), p(rec_b[1]), p(rec_b[2]), p(rec_b[3]),
-        6, 0, *[p(t) for t in out_b], None, stream), "project_backward_finish")
+        6, 0, *[p(t) for t in out_b], None, None, None, stream), "project_backward_finish")
     torch.cuda.synchronize()
+    if bookkeeping == 0:
+        # multi-GPU form: straight into the exchange buffer == two calls + vings_splat_pack_exchange
+        cols = L.vings_splat_pack_columns()
+        keys0 = torch.randint(0, 1 << 40, (n, 2), generator=torch.Generator().manual_seed(2)).to(dev)
+        pk_a, keys_a = torch.empty((cols, n), device=dev), keys0.clone()
+        _lib.check(L.vings_splat_pack_exchange(n, *[p(t) for t in out_a], p(cur), 5, p(pk_a), p(keys_a),
+                                               stream), "pack_exchange")
+        pk_b, keys_b = torch.empty((cols, n), device=dev), keys0.clone()
+        _lib.check(L.vings_surfel_project_backward_finish(
+            n, H, W, 1.0, p(xyz), p(scales), p(rot), p(aux[0]), p(aux[1]), p(st.radii), p(dgeom),
+            p(opac), p(raw["_rotation"]), p(stable), p(rec_b[0]), None, None, None, 5, 0,
+            None, None, None, None, None, None, None, p(pk_b), p(keys_b), stream),
+            "project_backward_finish (packed)")
+        torch.cuda.synchronize()
+        assert torch.equal(pk_a, pk_b) and torch.equal(keys_a, keys_b)
+        assert not torch.equal(keys_a, keys0)
 
 
 def test_projection_with_inline_activation_equals_activate_then_project():

@@ -38,7 +38,7 @@ _SIGNATURES = {
                                 [_c.c_int, _P]),
     "vings_splat_activate": (_c.c_int, [_c.c_int] + [_P] * 7),
     "vings_surfel_project_backward_finish": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float] +
-                                             [_P] * 14 + [_c.c_int64, _c.c_int] + [_P] * 8),
+                                             [_P] * 14 + [_c.c_int64, _c.c_int] + [_P] * 10),
     "vings_splat_grad_finish": (_c.c_int, [_c.c_int] + [_P] * 15 + [_c.c_int64, _c.c_int] + [_P] * 7),
     "vings_surfel_blend_importance": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int] + [_P] * 5 +
                                       [_c.c_int, _P, _P, _P]),

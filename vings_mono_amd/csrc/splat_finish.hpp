@@ -22,6 +22,10 @@ struct FinishArgs {
     uint8_t* visible;
     int64_t this_kf;
     int bookkeeping;
+    // Multi-GPU: when `packed` is set the weighted gradients, s0 and the visibility flag go
+    // straight into the planar exchange buffer (packed[c * N + i], 15 columns) instead of g_*
+    // and `visible`, and the record keys are folded into record_keys [N,2] (see splat_step.hip).
+    float* packed; long long* record_keys; int N;
 };
 
 // dm / dc / dop / ds / g: gradients w.r.t. the position, colour and the ACTIVATED opacity,
@@ -40,16 +44,11 @@ __device__ __forceinline__ void splat_finish(int i, const FinishArgs& a, const f
         if (a.kf_max_scores[i] < s0) { a.kf_max_scores[i] = s0; a.kf_id[i] = a.this_kf; }
     }
     const bool stable = a.stable_mask && a.stable_mask[i];
-    a.visible[i] = (a.radii[i] > 0 && !stable) ? 1 : 0;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        a.g_xyz[3 * i + k] = dm[k] * w;
-        a.g_rgb[3 * i + k] = dc[k] * w;
-    }
+    const bool vis = a.radii[i] > 0 && !stable;
     const float o = a.opacities[i];
-    a.g_opacity[i] = dop * (o * (1.0f - o)) * w;          // sigmoid'
+    const float g_op = dop * (o * (1.0f - o)) * w;          // sigmoid'
     const float2 s = reinterpret_cast<const float2*>(a.scales)[i];
-    reinterpret_cast<float2*>(a.g_scaling)[i] = make_float2(ds.x * s.x * w, ds.y * s.y * w);  // exp'
+    const float2 g_sc = make_float2(ds.x * s.x * w, ds.y * s.y * w);  // exp'
     // x / max(|x|, eps): d/dx = (g - n (n.g)) / |x|
     const float4 q = reinterpret_cast<const float4*>(a.raw_rotation)[i];
     const float len = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
@@ -65,6 +64,26 @@ __device__ __forceinline__ void splat_finish(int i, const FinishArgs& a, const f
         const float k = 1e12f * w;
         out = make_float4(g.x * k, g.y * k, g.z * k, g.w * k);
     }
+    if (a.packed) {
+        const float v[15] = {dm[0] * w, dm[1] * w, dm[2] * w, dc[0] * w, dc[1] * w, dc[2] * w, g_op,
+                             g_sc.x, g_sc.y, out.x, out.y, out.z, out.w, s0, vis ? 1.f : 0.f};
+#pragma unroll
+        for (int c = 0; c < 15; ++c) a.packed[(size_t)c * a.N + i] = v[c];
+        const long long b0 = (long long)__float_as_uint(fmaxf(s0, 0.f));
+        const long long b1 = (long long)__float_as_uint(fmaxf(s1, 0.f));
+        const long long k0 = (b0 << 32) | ((long long)a.this_kf & 0xFFFFFFFFll);
+        a.record_keys[2 * i] = max(a.record_keys[2 * i], k0);
+        a.record_keys[2 * i + 1] = max(a.record_keys[2 * i + 1], b1);
+        return;
+    }
+    a.visible[i] = vis ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        a.g_xyz[3 * i + k] = dm[k] * w;
+        a.g_rgb[3 * i + k] = dc[k] * w;
+    }
+    a.g_opacity[i] = g_op;
+    reinterpret_cast<float2*>(a.g_scaling)[i] = g_sc;
     reinterpret_cast<float4*>(a.g_rotation)[i] = out;
 }
 

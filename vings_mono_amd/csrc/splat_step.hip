@@ -145,7 +145,7 @@ extern "C" int vings_splat_grad_finish(
     VINGS_REQUIRE((((uintptr_t)raw_rotation | (uintptr_t)d_rotations | (uintptr_t)g_rotation) & 15) == 0 &&
                       (((uintptr_t)scales | (uintptr_t)d_scales | (uintptr_t)g_scaling) & 7) == 0,
                   "rotation arrays must be 16-byte aligned, scaling arrays 8-byte aligned");
-    FinishArgs a;
+    FinishArgs a = {};
     a.opacities = opacities; a.scales = scales; a.raw_rotation = raw_rotation;
     a.d_means3D = d_means3D; a.d_colors = d_colors; a.d_opacities = d_opacities;
     a.d_scales = d_scales; a.d_rotations = d_rotations; a.cur_scores = cur_scores;

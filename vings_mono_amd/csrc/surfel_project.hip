@@ -570,13 +570,16 @@ extern "C" int vings_surfel_project_backward_finish(
     const float* dgeom, const float* opacities, const float* raw_rotation,
     const uint8_t* stable_mask, float* global_scores, float* local_scores, float* kf_max_scores,
     int64_t* kf_id, int64_t this_kf, int bookkeeping, float* g_xyz, float* g_rgb, float* g_opacity,
-    float* g_scaling, float* g_rotation, uint8_t* visible, float* scores_grad, void* stream) {
+    float* g_scaling, float* g_rotation, uint8_t* visible, float* scores_grad, float* packed,
+    int64_t* record_keys, void* stream) {
     VINGS_REQUIRE(N >= 0 && H > 0 && W > 0, "sizes");
     if (N == 0) return VINGS_OK;
     VINGS_REQUIRE(means3D && scales && rotations && viewmatrix && projmatrix && radii && dgeom &&
                       opacities && raw_rotation && global_scores,
                   "null input");
-    VINGS_REQUIRE(g_xyz && g_rgb && g_opacity && g_scaling && g_rotation && visible, "null output");
+    VINGS_REQUIRE(packed ? (record_keys != nullptr && !bookkeeping)
+                         : (g_xyz && g_rgb && g_opacity && g_scaling && g_rotation && visible),
+                  "null output (packed needs record_keys and bookkeeping = 0)");
     VINGS_REQUIRE(!bookkeeping || (local_scores && kf_max_scores && kf_id),
                   "bookkeeping needs the score arrays");
     VINGS_REQUIRE((((uintptr_t)raw_rotation | (uintptr_t)rotations | (uintptr_t)g_rotation |
@@ -590,6 +593,7 @@ extern "C" int vings_surfel_project_backward_finish(
     a.g_xyz = g_xyz; a.g_rgb = g_rgb; a.g_opacity = g_opacity; a.g_scaling = g_scaling;
     a.g_rotation = g_rotation; a.visible = visible; a.this_kf = this_kf;
     a.bookkeeping = bookkeeping;
+    a.packed = packed; a.record_keys = reinterpret_cast<long long*>(record_keys); a.N = N;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PROF_PROJECT_BWD, s);
     project_bwd_finish_kernel<<<cdiv(N, 256), 256, 0, s>>>(

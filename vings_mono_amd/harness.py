@@ -306,7 +306,6 @@ class SurfelMapper:
             n, dev = self.n, self.device
             e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)
             fb = {"opac": e(n, 1), "scales": e(n, 2), "rot": e(n, 4), "vis": e(n, dt=torch.uint8),
-                  "cur": e(n, 2),
                   "grads": {k: torch.zeros_like(self.params[k]) for k in self.NAMES}}
             for k in self.NAMES:
                 self.params[k].grad = fb["grads"][k]   # the optimiser reads .grad
@@ -334,7 +333,6 @@ class SurfelMapper:
                                                          self.loss_weights)
             single = reducer is None or reducer.world == 1
             g = fb["grads"]
-            cur = fb["cur"]
             view, proj = aux[0], aux[1]
             dgeom = surfel.blend_backward(st, aux, d_rgb, d_allmap)
             # per-splat backward + chain rule through the activations + score weighting +
@@ -345,16 +343,14 @@ class SurfelMapper:
                 ptr(self.stable_mask.view(torch.uint8)), ptr(self.global_scores),
                 ptr(self.local_scores), ptr(self.globalkf_max_scores), ptr(self.globalkf_id),
                 int(kf_id), 1 if single else 0, ptr(g["_xyz"]), ptr(g["_rgb"]), ptr(g["_opacity"]),
-                ptr(g["_scaling"]), ptr(g["_rotation"]), ptr(fb["vis"]),
-                None if single else ptr(cur), stream),
+                ptr(g["_scaling"]), ptr(g["_rotation"]), ptr(fb["vis"]), None,
+                None if single else ptr(reducer.fbuf),
+                None if single else ptr(self._record_keys()), stream),
                 "vings_surfel_project_backward_finish")
             vis = fb["vis"]
             if not single:
-                # pack -> SUM all-reduce over the replicas -> unpack + score sums
+                # (packed by the kernel above) -> SUM all-reduce over the replicas -> unpack
                 grad_ptrs = [ptr(g[k]) for k in self.NAMES]
-                _lib.check(L.vings_splat_pack_exchange(
-                    n, *grad_ptrs, ptr(vis), ptr(cur), int(kf_id), ptr(reducer.fbuf),
-                    ptr(self._record_keys()), stream), "vings_splat_pack_exchange")
                 reducer.all_reduce_packed()
                 _lib.check(L.vings_splat_unpack_exchange(
                     n, ptr(reducer.fbuf), ptr(self.global_scores), ptr(self.local_scores),
