@@ -315,7 +315,7 @@ class SurfelMapper:
     def fused_view(self, settings, intr, gt, Rw2c_host, kf_id=0, reducer=None):
         """The same view step as backward_view + finish_view with no PyTorch op in it:
         activations, rasteriser forward, loss, rasteriser backward, chain rule + score
-        weighting + bookkeeping, sparse Adam — 30 HIP launches through the C ABI.
+        weighting + bookkeeping, sparse Adam — about 22 HIP launches through the C ABI.
         `settings` is the view's GaussianRasterizationSettings (see `view_settings`)."""
         from . import _lib, surfel
         L = _lib.lib()
