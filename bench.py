@@ -82,7 +82,7 @@ def main():
     if args.rehearse_gloo:
         local_rank = 0
         import faulthandler
-        faulthandler.dump_traceback_later(100, exit=True)      # a stuck rehearsal names its line
+        faulthandler.dump_traceback_later(90, exit=True)       # a stuck rehearsal names its line
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:

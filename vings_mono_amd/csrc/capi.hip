@@ -15,6 +15,16 @@ void set_error(const char* fmt, ...) {
 }  // namespace vings
 
 extern "C" const char* vings_last_error(void) { return vings::g_err; }
+namespace vings {
+bool trace_sync() {
+    static const bool on = [] {
+        const char* e = getenv("VINGS_TRACE_SYNC");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+}  // namespace vings
+
 extern "C" int vings_abi_version(void) { return 3; }
 
 // ---------------------------------------------------------------------------

@@ -1,6 +1,8 @@
 // Shared host/device helpers for libvings_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <unistd.h>
+#include <cstdio>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -28,7 +30,19 @@ void set_error(const char* fmt, ...);
         }                                                                                 \
     } while (0)
 
-#define VINGS_LAUNCH_CHECK() VINGS_CHECK_HIP(hipGetLastError())
+// With VINGS_TRACE_SYNC=1 in the environment every launch is followed by a device
+// synchronisation and logged to stderr before and after it: a kernel that never finishes is
+// the last "queued" line without its "done".
+bool trace_sync();
+#define VINGS_LAUNCH_CHECK()                                                              \
+    do {                                                                                  \
+        VINGS_CHECK_HIP(hipGetLastError());                                               \
+        if (::vings::trace_sync()) {                                                      \
+            fprintf(stderr, "[vings %d] %s:%d queued\n", (int)getpid(), __FILE__, __LINE__); \
+            VINGS_CHECK_HIP(hipDeviceSynchronize());                                      \
+            fprintf(stderr, "[vings %d] %s:%d done\n", (int)getpid(), __FILE__, __LINE__); \
+        }                                                                                 \
+    } while (0)
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

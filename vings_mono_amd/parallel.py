@@ -54,20 +54,30 @@ class GradReducer:
         if world > 1:
             self.fbuf = torch.zeros((PACK_WIDTH, n), dtype=torch.float32, device=device)
 
-    def _ready(self, t):
-        """gloo stages device tensors through host memory; on this ROCm stack that copy stalls
-        for good when it is queued behind kernels still running, so wait for them first.  RCCL
-        runs on the device and orders itself after the current stream."""
+    class _Done:
+        """Handle of a collective that has already completed."""
+        def wait(self):
+            return True
+
+    def _all_reduce(self, t, op, async_op=False):
+        """RCCL reduces device tensors in place on its own stream, ordered after the current
+        one.  gloo works on host memory: a device tensor is staged through the host here, in
+        the calling thread (its own staging of device tensors, done from a worker thread, was
+        seen to stall the GPU queue of a process for good when several processes share one
+        card, which is how the tests run two ranks on a one-GPU box)."""
         import torch.distributed as dist
         if t.is_cuda and dist.get_backend(self.group) == "gloo":
-            torch.cuda.current_stream(t.device).synchronize()
+            h = t.cpu()                       # waits for the kernels that produced t
+            dist.all_reduce(h, op=op, group=self.group)
+            t.copy_(h)
+            return self._Done() if async_op else None
+        return dist.all_reduce(t, op=op, group=self.group, async_op=async_op)
 
     def all_reduce_packed(self):
         """SUM over `fbuf`, already filled on the device (the fused view step packs it with one
         kernel)."""
         import torch.distributed as dist
-        self._ready(self.fbuf)
-        dist.all_reduce(self.fbuf, op=dist.ReduceOp.SUM, group=self.group)
+        self._all_reduce(self.fbuf, dist.ReduceOp.SUM)
 
     def all_reduce_record_keys(self, keys, async_op=False):
         """MAX over the ranks of the running record keys ([N,2] int64), in place.  With
@@ -75,8 +85,7 @@ class GradReducer:
         if self.world == 1:
             return None
         import torch.distributed as dist
-        self._ready(keys)
-        return dist.all_reduce(keys, op=dist.ReduceOp.MAX, group=self.group, async_op=async_op)
+        return self._all_reduce(keys, dist.ReduceOp.MAX, async_op=async_op)
 
     def reduce(self, grads, cur, vis_local):
         """grads: dict name -> [N,M] tensor (updated in place with the sum over ranks).
