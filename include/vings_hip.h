@@ -82,6 +82,17 @@ int vings_surfel_project(int N, int H, int W, float scale_modifier,
                          int64_t* num_instances_host, uint32_t* depth_bits_range_host,
                          void* stream);
 
+/* Which tiles a splat is binned into (process-wide switch, returns the previous value).
+ * 0: every tile of the reference's square of side 2*radius about the splat centre (getRect in
+ *    the rasteriser's auxiliary.h, called from forward.cu preprocessCUDA): rect, tiles_touched,
+ *    the instance count D, keys and ranges are then exactly the reference's.
+ * 1 (default): only the tiles of that square which the splat's alpha >= 1/255 box reaches.
+ *    The blend passes reject the other tiles with the very same comparisons before they
+ *    evaluate a pixel, so colour, allmap, radii and all gradients are unchanged; the instance
+ *    list is the subset of the reference's list in the same order (about 30 % shorter on the
+ *    benchmark scene), and n_contrib counts positions in the shorter list. */
+int vings_surfel_set_tight_binning(int on);
+
 /* The same call in two halves, for callers that do not want the GPU to idle while the host
  * learns D: launch returns at once; wait blocks until the projection launched last on the
  * current GPU has finished (on an event behind it, not on the whole stream) and returns its

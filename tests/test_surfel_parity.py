@@ -20,6 +20,17 @@ from vings_mono_amd import surfel, synth
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["reference_binning", "tight_binning"])
+def tight(request):
+    """Every test of this file runs under both binning modes: the reference's 3-sigma square
+    (instance list compared bit for bit with the oracle's) and the default alpha-box binning
+    (a subset of that list; every rendered value and gradient held to the same bars)."""
+    on = request.param == "tight_binning"
+    prev = surfel.set_tight_binning(on)
+    yield on
+    surfel.set_tight_binning(prev)
+
 RTOL = 1e-4
 
 
@@ -88,21 +99,35 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES)
-def test_forward_parity(case, oracle32, oracle64):
+def test_forward_parity(case, oracle32, oracle64, tight):
     dev = torch.device("cuda:0")
     sc = scene(**case)
     ref = oracle_forward(oracle32, sc)
     inp, st, _ = run_forward(sc, dev)
     # ---- bit-exact integer work ----
     np.testing.assert_array_equal(st.radii.cpu().numpy(), ref["radii"])
-    np.testing.assert_array_equal(st.tiles_touched.cpu().numpy().view(np.uint32)[:sc["means3D"].shape[0]],
-                                  ref["tiles_touched"])
-    np.testing.assert_array_equal(st.rect.cpu().numpy()[:sc["means3D"].shape[0]], ref["rect"])
-    assert st.D == ref["D"]
-    D = ref["D"]
-    np.testing.assert_array_equal(st.keys.cpu().numpy().view(np.uint64)[:D], ref["keys"])
-    np.testing.assert_array_equal(st.vals.cpu().numpy().view(np.uint32)[:D], ref["vals"])
-    np.testing.assert_array_equal(st.ranges.cpu().numpy().view(np.uint32), ref["ranges"])
+    if not tight:
+        np.testing.assert_array_equal(st.tiles_touched.cpu().numpy().view(np.uint32)[:sc["means3D"].shape[0]],
+                                      ref["tiles_touched"])
+        np.testing.assert_array_equal(st.rect.cpu().numpy()[:sc["means3D"].shape[0]], ref["rect"])
+        assert st.D == ref["D"]
+        D = ref["D"]
+        np.testing.assert_array_equal(st.keys.cpu().numpy().view(np.uint64)[:D], ref["keys"])
+        np.testing.assert_array_equal(st.vals.cpu().numpy().view(np.uint32)[:D], ref["vals"])
+        np.testing.assert_array_equal(st.ranges.cpu().numpy().view(np.uint32), ref["ranges"])
+    else:
+        # a subset of the reference's instance list, in the reference's order
+        D = st.D
+        assert 0 < D <= ref["D"]
+        n = np.int64(sc["means3D"].shape[0])
+        pair = lambda keys, vals: (keys >> np.uint64(32)).astype(np.int64) * n + vals.astype(np.int64)
+        mine = pair(st.keys.cpu().numpy().view(np.uint64)[:D], st.vals.cpu().numpy().view(np.uint32)[:D])
+        theirs = pair(ref["keys"], ref["vals"])                 # one id per (tile, splat)
+        sorter = np.argsort(theirs, kind="stable")
+        at = np.searchsorted(theirs, mine, sorter=sorter)
+        assert (at < theirs.shape[0]).all()
+        pos = sorter[at]
+        assert (theirs[pos] == mine).all() and (np.diff(pos) > 0).all()
     vis = ref["radii"] > 0
     np.testing.assert_array_equal(st.depth.cpu().numpy()[:vis.shape[0]][vis], ref["depth"][vis])
     geom = st.geom.cpu().numpy()[:vis.shape[0]]
@@ -134,7 +159,10 @@ def test_forward_parity(case, oracle32, oracle64):
     assert e_hip <= 2.0 * e_f32 + 1e-6 * np.sqrt(ref64.size), (e_hip, e_f32)
     assert_close_maps("final_T", st.final_T.cpu().numpy(), ref["final_T"])
     nc = st.n_contrib.cpu().numpy().view(np.uint32)
-    assert (nc == ref["n_contrib"]).mean() >= 0.9995
+    if not tight:
+        assert (nc == ref["n_contrib"]).mean() >= 0.9995
+    else:
+        assert (nc <= ref["n_contrib"]).mean() >= 0.9995      # positions in the shorter list
 
 
 def test_forward_empty_and_culled(oracle32):
@@ -332,3 +360,28 @@ def test_speculative_launch_equals_exact_launch():
     assert want_none.D == 0
     _same_state(want_none, _forward_state(small, W, H, look_away=True))   # nothing in view
     _same_state(want_small, _forward_state(small, W, H))        # the hint survives an empty view
+
+
+def test_tight_binning_renders_the_same_bits(tight):
+    """The two binning modes on one scene: colour, allmap, final transmittance and radii are
+    bit-identical, the tight list is shorter, and every instance it drops is one the alpha box
+    of its splat does not reach (recomputed here from the stored box and the tile origin)."""
+    if not tight:
+        pytest.skip("compares the two modes itself; one run is enough")
+    W, H = 320, 192
+    raw = synth.make_splats(20000, W, H, n_views=2, seed=43, z_range=(1.5, 30.0))
+    surfel.set_tight_binning(False)
+    a = _forward_state(raw, W, H)
+    surfel.set_tight_binning(True)
+    b = _forward_state(raw, W, H)
+    assert b.D < a.D
+    for name in ("radii", "color", "allmap", "final_T", "depth"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    gx = (W + 15) // 16
+    ka, va = a.keys[:a.D], a.vals[:a.D].long()
+    tile = (ka >> 32)
+    tx0, ty0 = (tile % gx).float() * 16, (tile // gx).float() * 16
+    box = a.geom[va][:, 20:24]                                   # xmin, xmax, ymin, ymax
+    reach = ~((box[:, 0] > tx0 + 15) | (box[:, 1] < tx0) | (box[:, 2] > ty0 + 15) | (box[:, 3] < ty0))
+    assert int(reach.sum()) == b.D
+    assert torch.equal(ka[reach], b.keys[:b.D]) and torch.equal(va[reach], b.vals[:b.D].long())

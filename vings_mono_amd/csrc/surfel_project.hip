@@ -10,6 +10,7 @@
 // /root/reference/scripts/gaussian/gaussian_base.py:193-203,382.
 #include <mutex>
 
+#include <atomic>
 #include "common.hpp"
 #include "splat_finish.hpp"
 
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     const float* __restrict__ proj, float* __restrict__ geom, float* __restrict__ depth,
     int32_t* __restrict__ radii, int32_t* __restrict__ rect, uint32_t* __restrict__ tiles_touched,
     uint32_t* __restrict__ block_counts, uint32_t* __restrict__ block_dmin,
-    uint32_t* __restrict__ block_dmax) {
+    uint32_t* __restrict__ block_dmax, int tight) {
     __shared__ uint32_t wsum[4], wmin[4], wmax[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     uint32_t touched = 0;
@@ -171,8 +172,6 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
         else dlo = dhi = __float_as_uint(dep);
         radii[i] = rad;
         depth[i] = dep;
-        tiles_touched[i] = touched;
-        reinterpret_cast<int4*>(rect)[i] = make_int4(x0, y0, x1, y1);
         if (ok) {
             float4* g = reinterpret_cast<float4*>(geom + (size_t)i * VINGS_GEOM_STRIDE);
             const float c0 = colors[3 * i], c1 = colors[3 * i + 1], c2 = colors[3 * i + 2];
@@ -214,7 +213,27 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
                 }
             }
             g[5] = make_float4(bx0, bx1, by0, by1);
+            if (tight) {
+                // Drop the tiles the alpha box cannot reach: exactly those every blend pass
+                // rejects for this splat with the same comparisons (stage_batch), so no
+                // rendered value changes; only the instance list gets shorter.
+                const float lo_x = fminf(fmaxf(bx0, -1e8f), 1e8f), hi_x = fminf(fmaxf(bx1, -1e8f), 1e8f);
+                const float lo_y = fminf(fmaxf(by0, -1e8f), 1e8f), hi_y = fminf(fmaxf(by1, -1e8f), 1e8f);
+                int a0 = max(x0, min(x1, (int)floorf((lo_x - 15.f) * (1.f / 16.f)) - 1));
+                int a1 = max(x0, min(x1, (int)floorf(hi_x * (1.f / 16.f)) + 2));
+                while (a0 < x1 && bx0 > 16.f * (float)a0 + 15.f) ++a0;
+                while (a1 > a0 && bx1 < 16.f * (float)(a1 - 1)) --a1;
+                int b0 = max(y0, min(y1, (int)floorf((lo_y - 15.f) * (1.f / 16.f)) - 1));
+                int b1 = max(y0, min(y1, (int)floorf(hi_y * (1.f / 16.f)) + 2));
+                while (b0 < y1 && by0 > 16.f * (float)b0 + 15.f) ++b0;
+                while (b1 > b0 && by1 < 16.f * (float)(b1 - 1)) --b1;
+                x0 = a0; x1 = max(a0, a1); y0 = b0; y1 = max(b0, b1);
+                touched = (uint32_t)((x1 - x0) * (y1 - y0));
+                if (touched == 0) { dlo = 0xFFFFFFFFu; dhi = 0u; }
+            }
         }
+        tiles_touched[i] = touched;
+        reinterpret_cast<int4*>(rect)[i] = make_int4(x0, y0, x1, y1);
     }
     // per-block instance count (feeds the exclusive scan over blocks)
     uint32_t s = wave_sum_u32(touched);
@@ -414,6 +433,9 @@ constexpr int kMaxDevices = 64;
 std::mutex g_mail_mu[kMaxDevices];
 uint32_t* g_mail[kMaxDevices] = {};
 hipEvent_t g_mail_evt[kMaxDevices] = {};
+// 1: a splat is binned only into the tiles its alpha >= 1/255 box reaches (the default);
+// 0: into every tile of the reference's 3-sigma square (forward.cu preprocess / getRect).
+std::atomic<int> g_tight_binning{1};
 }  // namespace
 
 }  // namespace vings
@@ -441,18 +463,19 @@ static int project_launch(int N, int H, int W, float scale_modifier, const float
     if (!g_mail[dev]) VINGS_CHECK_HIP(hipHostMalloc((void**)&g_mail[dev], 64, hipHostMallocDefault));
     if (!g_mail_evt[dev]) VINGS_CHECK_HIP(hipEventCreateWithFlags(&g_mail_evt[dev], hipEventDisableTiming));
     const int nb = cdiv(N, 256);
+    const int tight = g_tight_binning.load(std::memory_order_relaxed);
     {
     ProfScope prof(PROF_PROJECT_FWD, s);
     if (act_scales)
         project_fwd_kernel<true><<<nb, 256, 0, s>>>(
             N, H, W, scale_modifier, means3D, scales, rotations, opacities, act_scales,
             act_rotations, act_opacities, colors, flow, viewmatrix, projmatrix, geom, depth, radii,
-            rect, tiles_touched, block_prefix, block_prefix + nb + 1, block_prefix + 2 * nb + 1);
+            rect, tiles_touched, block_prefix, block_prefix + nb + 1, block_prefix + 2 * nb + 1, tight);
     else
         project_fwd_kernel<false><<<nb, 256, 0, s>>>(
             N, H, W, scale_modifier, means3D, scales, rotations, opacities, nullptr, nullptr,
             nullptr, colors, flow, viewmatrix, projmatrix, geom, depth, radii, rect, tiles_touched,
-            block_prefix, block_prefix + nb + 1, block_prefix + 2 * nb + 1);
+            block_prefix, block_prefix + nb + 1, block_prefix + 2 * nb + 1, tight);
     VINGS_LAUNCH_CHECK();
     }
     scan_blocks_kernel<<<1, 1024, 0, s>>>(block_prefix, nb, g_mail[dev]);
@@ -529,6 +552,10 @@ extern "C" int vings_surfel_project_launch_activate(
                           colors, flow, viewmatrix, projmatrix, geom, depth, radii, rect,
                           tiles_touched, block_prefix, (hipStream_t)stream, &dev, scales, rotations,
                           opacities);
+}
+
+extern "C" int vings_surfel_set_tight_binning(int on) {
+    return g_tight_binning.exchange(on ? 1 : 0);
 }
 
 extern "C" int vings_surfel_project_wait(int64_t* num_instances_host,

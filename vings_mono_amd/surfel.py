@@ -56,6 +56,14 @@ class SurfelForwardState:
                  "allmap")
 
 
+def set_tight_binning(on):
+    """Bin splats only into the tiles their alpha >= 1/255 box reaches (True, the default) or
+    into the reference's full 3-sigma square (False: instance list identical to the
+    reference's).  Rendered values and gradients are the same either way.  Returns the
+    previous setting."""
+    return bool(_lib.lib().vings_surfel_set_tight_binning(1 if on else 0))
+
+
 def rasterize_forward(means3D, colors, opacities, scales, rotations, settings, keep_keys=False,
                       raw=None):
     """Run projection -> binning -> blend. Returns (SurfelForwardState, aux).
