@@ -57,23 +57,46 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-// Pixel classes of the ground truth, one byte per pixel: the three later kernels read this
-// instead of re-deriving it from four float planes each.
+// Pixel classes of the ground truth, one byte per pixel, written by ssim_fwd_kernel (every
+// pixel belongs to exactly one of its tiles) together with the two class counts: the later
+// kernels read these instead of re-deriving them from four float planes each.
 constexpr uint8_t kPixValid = 1, kPixSky = 2;
 
-__global__ __launch_bounds__(256) void loss_count_kernel(size_t HW, const float* __restrict__ gt_rgb,
-                                                         const float* __restrict__ gt_depth,
-                                                         LossSums* __restrict__ sums,
-                                                         uint8_t* __restrict__ cls) {
-    unsigned nv = 0, ns = 0;
-    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < HW; p += (size_t)gridDim.x * 256) {
-        const bool sky = is_sky(gt_rgb, HW, p);
-        const bool valid = (!sky) && gt_depth[p] > 0.0f;
-        ns += sky;
-        nv += valid;
-        cls[p] = sky ? kPixSky : (valid ? kPixValid : 0);
-    }
+// SSIM forward: per colour channel, moments through a separable Gaussian with zero
+// padding.  maps[(3*ch + m) * HW + p], m = 0..2: valid(p) * d ssim / d {mu_x, E[xx], E[xy]}.
+__global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, Gauss gw,
+                                                       const float* __restrict__ rgb,
+                                                       const float* __restrict__ gt_rgb,
+                                                       const float* __restrict__ gt_depth,
+                                                       uint8_t* __restrict__ cls,
+                                                       LossSums* __restrict__ sums,
+                                                       float* __restrict__ maps,
+                                                       double* __restrict__ partials) {
+    __shared__ float sx[kSIn][kSIn + 1], sy[kSIn][kSIn + 1];
+    __shared__ float hz[5][kSIn][kST + 1];
+    __shared__ double red[4];
     __shared__ unsigned cnt[2][4];
+    const size_t HW = (size_t)H * W;
+    const int tx0 = blockIdx.x * kST, ty0 = blockIdx.y * kST;
+    const int c = threadIdx.x & 31, rq = threadIdx.x >> 5;  // output column, first output row
+    double ssim_acc = 0.0, l1_acc = 0.0;
+    // validity of this lane's four output pixels: rows 4 rq .. 4 rq + 3 of column c, so the
+    // vertical filter reads 14 rows of the horizontal result for 4 outputs instead of 44
+    bool vld[4];
+    unsigned nv = 0, ns = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gy = ty0 + 4 * rq + i, gx = tx0 + c;
+        vld[i] = false;
+        if (gy < H && gx < W) {
+            const size_t p = (size_t)gy * W + gx;
+            const bool sky = is_sky(gt_rgb, HW, p);
+            vld[i] = (!sky) && gt_depth[p] > 0.0f;
+            cls[p] = sky ? kPixSky : (vld[i] ? kPixValid : 0);
+            ns += sky;
+            nv += vld[i];
+        }
+    }
     nv = wave_sum_u32(nv);
     ns = wave_sum_u32(ns);
     if ((threadIdx.x & 63) == 0) { cnt[0][threadIdx.x >> 6] = nv; cnt[1][threadIdx.x >> 6] = ns; }
@@ -83,35 +106,6 @@ __global__ __launch_bounds__(256) void loss_count_kernel(size_t HW, const float*
         ns = cnt[1][0] + cnt[1][1] + cnt[1][2] + cnt[1][3];
         if (nv) atomicAdd(&sums->n_valid, nv);
         if (ns) atomicAdd(&sums->n_sky, ns);
-    }
-}
-
-// SSIM forward: per colour channel, moments through a separable Gaussian with zero
-// padding.  maps[(3*ch + m) * HW + p], m = 0..2: valid(p) * d ssim / d {mu_x, E[xx], E[xy]}.
-__global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, Gauss gw,
-                                                       const float* __restrict__ rgb,
-                                                       const float* __restrict__ gt_rgb,
-                                                       const uint8_t* __restrict__ cls,
-                                                       float* __restrict__ maps,
-                                                       double* __restrict__ partials) {
-    __shared__ float sx[kSIn][kSIn + 1], sy[kSIn][kSIn + 1];
-    __shared__ float hz[5][kSIn][kST + 1];
-    __shared__ double red[4];
-    const size_t HW = (size_t)H * W;
-    const int tx0 = blockIdx.x * kST, ty0 = blockIdx.y * kST;
-    const int c = threadIdx.x & 31, rq = threadIdx.x >> 5;  // output column, first output row
-    double ssim_acc = 0.0, l1_acc = 0.0;
-    // validity of this lane's four output pixels: rows 4 rq .. 4 rq + 3 of column c, so the
-    // vertical filter reads 14 rows of the horizontal result for 4 outputs instead of 44
-    bool vld[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gy = ty0 + 4 * rq + i, gx = tx0 + c;
-        vld[i] = false;
-        if (gy < H && gx < W) {
-            const size_t p = (size_t)gy * W + gx;
-            vld[i] = cls[p] == kPixValid;
-        }
     }
     for (int ch = 0; ch < 3; ++ch) {
         const float* __restrict__ X = rgb + ch * HW;
@@ -569,10 +563,9 @@ extern "C" int vings_mapping_loss(int H, int W, const float* rgb, const float* a
 
     ProfScope prof(PROF_LOSS, s);
     VINGS_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(LossSums), s));
-    loss_count_kernel<<<min(cdiv((int64_t)HW, 1024), 1024), 256, 0, s>>>(HW, gt_rgb, gt_depth, sums, cls);
-    VINGS_LAUNCH_CHECK();
     const dim3 sgrid(cdiv(W, kST), cdiv(H, kST));
-    ssim_fwd_kernel<<<sgrid, 256, 0, s>>>(H, W, gw, rgb, gt_rgb, cls, maps, ssim_parts);
+    ssim_fwd_kernel<<<sgrid, 256, 0, s>>>(H, W, gw, rgb, gt_rgb, gt_depth, cls, sums, maps,
+                                          ssim_parts);
     VINGS_LAUNCH_CHECK();
     ssim_bwd_kernel<<<sgrid, 256, 0, s>>>(H, W, gw, w_rgb, rgb, gt_rgb, cls, maps, sums,
                                           dL_drgb);

@@ -145,7 +145,7 @@ LOSS_WEIGHT_ORDER = ("rgb_loss", "depth_loss", "alpha_loss", "normal_loss", "dis
 
 def mapping_loss_hip(rgb, allmap, gt, Rw2c_host, intr, weights=DEFAULT_LOSS_WEIGHTS):
     """`mapping_loss(postprocess(...))` and its gradient w.r.t. the rasteriser outputs in
-    five HIP launches (csrc/mapping_loss.hip) instead of a PyTorch graph.
+    four HIP launches (csrc/mapping_loss.hip) instead of a PyTorch graph.
 
     rgb [3,H,W], allmap [9,H,W]: rasteriser outputs (device); gt: dict with rgb [3,H,W],
     depth [1,H,W], depth_cov [1,H,W]; Rw2c_host: 3x3 CPU tensor (rotation of w2c).
