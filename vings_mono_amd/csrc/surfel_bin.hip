@@ -73,10 +73,22 @@ __global__ __launch_bounds__(256) void emit_keys_kernel(
         for (int step = 128; step > 0; step >>= 1)
             if (start[lo + step] <= q) lo += step;
         const int4 r = srect[lo];
-        const uint32_t idx = q - start[lo];
-        const uint32_t wd = (uint32_t)(r.z - r.x);
-        const uint32_t row = idx / wd;
-        const uint32_t tile = (uint32_t)(r.y + (int)row) * gx + (uint32_t)r.x + (idx - row * wd);
+        uint32_t idx = q - start[lo];
+        uint32_t tile;
+        if (r.x < 0) {
+            // packed form: origin, width and one bit per tile of the rectangle (row-major);
+            // slot idx is the idx-th set bit
+            unsigned long long bits = ((unsigned long long)(uint32_t)r.w << 32) | (uint32_t)r.z;
+            for (uint32_t k = 0; k < idx; ++k) bits &= bits - 1ull;
+            const uint32_t t = (uint32_t)__builtin_ctzll(bits);
+            const uint32_t wd = (uint32_t)r.y, row = t / wd;
+            const uint32_t x0 = (uint32_t)r.x & 0x7FFFu, y0 = ((uint32_t)r.x >> 15) & 0xFFFFu;
+            tile = (y0 + row) * gx + x0 + (t - row * wd);
+        } else {
+            const uint32_t wd = (uint32_t)(r.z - r.x);
+            const uint32_t row = idx / wd;
+            tile = (uint32_t)(r.y + (int)row) * gx + (uint32_t)r.x + (idx - row * wd);
+        }
         keys[out0 + q] = ((uint64_t)tile << low_bits) | (uint64_t)sdepth[lo];
         vals[out0 + q] = (uint32_t)(blockIdx.x * 256 + lo);
     }

@@ -13,6 +13,7 @@
 #include <atomic>
 #include "common.hpp"
 #include "splat_finish.hpp"
+#include "blend_cull.hpp"
 
 namespace vings {
 
@@ -112,10 +113,15 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     const int i = blockIdx.x * 256 + threadIdx.x;
     uint32_t touched = 0;
     uint32_t dlo = 0xFFFFFFFFu, dhi = 0u;   // float bits of the depth of a binned splat
+    __shared__ float4 srec[256 * 6];        // records of the splats whose tiles get tested
+    __shared__ int4 sgeo[256];
+    uint32_t cand = 0;                      // tiles of this lane's splat to test (0: none)
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    int4 packed_rect = make_int4(0, 0, 0, 0);
+    bool is_packed = false;
     if (i < N) {
         const int gx = (W + 15) / 16, gy = (H + 15) / 16;
         int32_t rad = 0;
-        int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
         float dep = 0.f;
         const PixProj B = pixel_projection(proj, W, H);
         SplatFrame f;
@@ -177,11 +183,12 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
             const float c0 = colors[3 * i], c1 = colors[3 * i + 1], c2 = colors[3 * i + 2];
             float fl0 = 0.f, fl1 = 0.f;
             if (flow) { fl0 = flow[2 * i]; fl1 = flow[2 * i + 1]; }
-            g[0] = make_float4(f.A[0][0], f.A[0][1], f.A[0][2], f.A[1][0]);
-            g[1] = make_float4(f.A[1][1], f.A[1][2], f.A[2][0], f.A[2][1]);
-            g[2] = make_float4(f.A[2][2], cx, cy, f.mult * f.n[0]);
-            g[3] = make_float4(f.mult * f.n[1], f.mult * f.n[2], o, c0);
-            g[4] = make_float4(c1, c2, fl0, fl1);
+            float4 rr[6];
+            rr[0] = make_float4(f.A[0][0], f.A[0][1], f.A[0][2], f.A[1][0]);
+            rr[1] = make_float4(f.A[1][1], f.A[1][2], f.A[2][0], f.A[2][1]);
+            rr[2] = make_float4(f.A[2][2], cx, cy, f.mult * f.n[0]);
+            rr[3] = make_float4(f.mult * f.n[1], f.mult * f.n[2], o, c0);
+            rr[4] = make_float4(c1, c2, fl0, fl1);
             // Conservative pixel box of alpha >= 1/255: alpha = o * exp(-rho/2) with
             // rho = min(rho3d, rho2d), so a pixel contributes only where rho <= rc.
             // {rho3d <= rc} is the projected ellipse of radius sqrt(rc) (same tangent-line
@@ -212,7 +219,9 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
                     bx0 = by0 = -1e30f; bx1 = by1 = 1e30f;   // crosses the camera plane: no bound
                 }
             }
-            g[5] = make_float4(bx0, bx1, by0, by1);
+            rr[5] = make_float4(bx0, bx1, by0, by1);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) g[k] = rr[k];
             if (tight) {
                 // Drop the tiles the alpha box cannot reach: exactly those every blend pass
                 // rejects for this splat with the same comparisons (stage_batch), so no
@@ -229,11 +238,62 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
                 while (b1 > b0 && by1 < 16.f * (float)(b1 - 1)) --b1;
                 x0 = a0; x1 = max(a0, a1); y0 = b0; y1 = max(b0, b1);
                 touched = (uint32_t)((x1 - x0) * (y1 - y0));
+                // Inside that rectangle the box is only the hull of the footprint: a tile
+                // none of whose four 8x8 blocks passes the blend passes' own conic test
+                // contributes nothing either.  Rectangles of up to 64 tiles get one bit per
+                // tile (row-major) from the workgroup step below; larger ones stay whole.
+                if (touched > 0 && touched <= 64u && x0 < 32768 && y0 < 32768) {
+                    cand = touched;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) srec[threadIdx.x * 6 + k] = rr[k];
+                }
                 if (touched == 0) { dlo = 0xFFFFFFFFu; dhi = 0u; }
             }
         }
+    }
+    if (tight) {
+        // The candidate tiles of the block's 256 splats, spread evenly over the lanes (a lane
+        // walking its own splat's rectangle would hold its whole wave for the largest one).
+        __shared__ uint32_t cstart[257];
+        __shared__ uint32_t cw[4];
+        __shared__ unsigned long long sbits[256];
+        const uint32_t inc = wave_scan_incl(cand);
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 63) cw[wv] = inc;
+        sbits[threadIdx.x] = 0ull;
+        __syncthreads();
+        uint32_t off = inc - cand;
+        for (int k = 0; k < wv; ++k) off += cw[k];
+        cstart[threadIdx.x] = off;
+        if (threadIdx.x == 255) cstart[256] = off + cand;
+        sgeo[threadIdx.x] = make_int4(x0, y0, x1 - x0, 0);
+        __syncthreads();
+        const uint32_t total = cstart[256];
+        for (uint32_t q = threadIdx.x; q < total; q += 256) {
+            int lo = 0;   // largest j with cstart[j] <= q; splats without candidates lose ties
+#pragma unroll
+            for (int step = 128; step > 0; step >>= 1)
+                if (cstart[lo + step] <= q) lo += step;
+            const int4 gq = sgeo[lo];
+            const int t = (int)(q - cstart[lo]);
+            const int ty = t / gq.z, tx = t - ty * gq.z;
+            const float4* rec = srec + lo * 6;
+            if (block_mask(rec, rec[5], (float)((gq.x + tx) * 16), (float)((gq.y + ty) * 16)) != 0u)
+                atomicOr(&sbits[lo], 1ull << t);
+        }
+        __syncthreads();
+        if (cand) {
+            const unsigned long long bits = sbits[threadIdx.x];
+            touched = (uint32_t)__popcll(bits);
+            packed_rect = make_int4((int)(0x80000000u | (uint32_t)x0 | ((uint32_t)y0 << 15)), x1 - x0,
+                                    (int)(uint32_t)bits, (int)(uint32_t)(bits >> 32));
+            is_packed = true;
+            if (touched == 0) { dlo = 0xFFFFFFFFu; dhi = 0u; }
+        }
+    }
+    if (i < N) {
         tiles_touched[i] = touched;
-        reinterpret_cast<int4*>(rect)[i] = make_int4(x0, y0, x1, y1);
+        reinterpret_cast<int4*>(rect)[i] = is_packed ? packed_rect : make_int4(x0, y0, x1, y1);
     }
     // per-block instance count (feeds the exclusive scan over blocks)
     uint32_t s = wave_sum_u32(touched);
