@@ -63,7 +63,7 @@ int vings_abi_version(void);
  *                  box[4] = xmin,xmax,ymin,ymax of the pixels the splat can reach with
  *                  alpha >= 1/255 (conservative; lets a wave skip the splat)}
  *                  (rows of culled splats are left untouched)
- *      depth[N] radii[N](int32) rect[N,4](int32 x0,y0,x1,y1 in tiles)
+ *      depth[N] radii[N](int32) rect[N,4](int32 x0,y0,x1,y1 in tiles; packed form under tight binning, see vings_surfel_set_tight_binning)
  *      tiles_touched[N](uint32)
  *      block_prefix[3*ceil(N/256)+4] (uint32): the first ceil(N/256)+1 entries are the
  *                  exclusive prefix of per-256-splat instance counts (last = total); the
