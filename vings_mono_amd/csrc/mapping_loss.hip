@@ -97,16 +97,6 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, Gauss gw,
             nv += vld[i];
         }
     }
-    nv = wave_sum_u32(nv);
-    ns = wave_sum_u32(ns);
-    if ((threadIdx.x & 63) == 0) { cnt[0][threadIdx.x >> 6] = nv; cnt[1][threadIdx.x >> 6] = ns; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        nv = cnt[0][0] + cnt[0][1] + cnt[0][2] + cnt[0][3];
-        ns = cnt[1][0] + cnt[1][1] + cnt[1][2] + cnt[1][3];
-        if (nv) atomicAdd(&sums->n_valid, nv);
-        if (ns) atomicAdd(&sums->n_sky, ns);
-    }
     for (int ch = 0; ch < 3; ++ch) {
         const float* __restrict__ X = rgb + ch * HW;
         const float* __restrict__ Y = gt_rgb + ch * HW;
@@ -197,9 +187,17 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, Gauss gw,
         }
         __syncthreads();
     }
-    const double s_tot = block_sum(ssim_acc, red);
+    // class counts last: the loads behind them overlap the first tile instead of stalling it
+    nv = wave_sum_u32(nv);
+    ns = wave_sum_u32(ns);
+    if ((threadIdx.x & 63) == 0) { cnt[0][threadIdx.x >> 6] = nv; cnt[1][threadIdx.x >> 6] = ns; }
+    const double s_tot = block_sum(ssim_acc, red);     // (has the barriers cnt needs)
     const double l_tot = block_sum(l1_acc, red);
     if (threadIdx.x == 0) {
+        nv = cnt[0][0] + cnt[0][1] + cnt[0][2] + cnt[0][3];
+        ns = cnt[1][0] + cnt[1][1] + cnt[1][2] + cnt[1][3];
+        if (nv) atomicAdd(&sums->n_valid, nv);
+        if (ns) atomicAdd(&sums->n_sky, ns);
         double* part = partials + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kSsimParts;
         part[0] = s_tot; part[1] = l_tot;
     }
