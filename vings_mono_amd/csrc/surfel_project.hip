@@ -321,28 +321,36 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(uint32_t* __restrict_
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
     if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int base = 0; base < nb; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = i < nb ? counts[i] : 0u;
-        const uint32_t inc = wave_scan_incl(v);
-        if (lane == 63) wtot[w] = inc;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int k = 0; k < w; ++k) woff += wtot[k];
-        const uint32_t carry = carry_s;
-        if (i < nb) counts[i] = carry + woff + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
-        __syncthreads();
-    }
-    // depth-bit range over the blocks; results live behind the per-block arrays:
-    // counts[3nb+1] = min, [3nb+2] = max, [3nb+3] = copy of the total
+    // depth-bit range over the blocks (independent of the scan: its loads are issued first);
+    // results live behind the per-block arrays: counts[3nb+1] = min, [3nb+2] = max,
+    // [3nb+3] = copy of the total
     uint32_t lo = 0xFFFFFFFFu, hi = 0u;
     for (int i = threadIdx.x; i < nb; i += 1024) {
         lo = min(lo, counts[nb + 1 + i]);
         hi = max(hi, counts[2 * nb + 1 + i]);
+    }
+    __syncthreads();
+    // four consecutive entries per lane: up to 4096 blocks (1 M splats) in one round
+    for (int base = 0; base < nb; base += 4096) {
+        const int i0 = base + 4 * (int)threadIdx.x;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = i0 + k < nb ? counts[i0 + k] : 0u;
+        const uint32_t mine = (v[0] + v[1]) + (v[2] + v[3]);
+        const uint32_t inc = wave_scan_incl(mine);
+        if (lane == 63) wtot[w] = inc;
+        __syncthreads();
+        uint32_t run = carry_s + inc - mine;
+        for (int k = 0; k < w; ++k) run += wtot[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k < nb) counts[i0 + k] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = run;
+        __syncthreads();
     }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
