@@ -113,13 +113,16 @@ int vings_surfel_project_launch(int N, int H, int W, float scale_modifier,
  * activations itself (scales = exp(raw_scaling), rotations = raw_rotation / max(|.|, 1e-12),
  * opacities = sigmoid(raw_opacity): gaussian_base.py:44-48,64-72; bit-identical to
  * vings_splat_activate) and leaves the activated arrays in scales / rotations / opacities for
- * the backward pass.  Saves the separate activation launch of the mapper's view step. */
+ * the backward pass.  Saves the separate activation launch of the mapper's view step.
+ * dgeom_clear (optional, [N, VINGS_GRAD_STRIDE]): the rows of the splats with radii > 0 are
+ * zeroed, ready for vings_surfel_blend_backward_accumulate (saves the clearing command of the
+ * backward pass; rows of culled splats are not touched and never read). */
 int vings_surfel_project_launch_activate(
     int N, int H, int W, float scale_modifier, const float* means3D, const float* raw_scaling,
     const float* raw_rotation, const float* raw_opacity, const float* colors, const float* flow,
     const float* viewmatrix, const float* projmatrix, float* scales, float* rotations,
     float* opacities, float* geom, float* depth, int32_t* radii, int32_t* rect,
-    uint32_t* tiles_touched, uint32_t* block_prefix, void* stream);
+    uint32_t* tiles_touched, uint32_t* block_prefix, float* dgeom_clear, void* stream);
 int vings_surfel_project_wait(int64_t* num_instances_host, uint32_t* depth_bits_range_host);
 
 /* Bytes of scratch vings_surfel_bin needs for D instances. */
@@ -176,6 +179,13 @@ int vings_surfel_blend_forward(int H, int W, const uint32_t* ranges, const uint3
  * it is zeroed by this call.
  */
 int vings_surfel_blend_backward(int N, int H, int W, const uint32_t* ranges,
+                                const uint32_t* vals_sorted, const float* geom, const float* bg,
+                                const uint8_t* pixel_mask, const float* final_T,
+                                const uint32_t* n_contrib, const float* dL_dcolor,
+                                const float* dL_dallmap, float* dgeom, void* stream);
+/* The same pass ADDING into dgeom instead of clearing it first: the caller supplies rows that
+ * are zero (vings_surfel_project_launch_activate can clear them) or hold gradients to add to. */
+int vings_surfel_blend_backward_accumulate(int N, int H, int W, const uint32_t* ranges,
                                 const uint32_t* vals_sorted, const float* geom, const float* bg,
                                 const uint8_t* pixel_mask, const float* final_T,
                                 const uint32_t* n_contrib, const float* dL_dcolor,

@@ -250,8 +250,13 @@ def test_projection_with_inline_activation_equals_activate_then_project():
     surfel._D_HINT.clear()
     for _ in range(2):
         o2, s2, r2 = (torch.full_like(t, 5.0) for t in (o1, s1, r1))
+        dg = torch.full((n, surfel.GRAD_STRIDE), 5.0, device=dev)
         got = surfel.rasterize_forward(raw["_xyz"], raw["_rgb"], o2, s2, r2, settings, keep_keys=True,
-                                       raw=(raw["_opacity"], raw["_scaling"], raw["_rotation"]))[0]
+                                       raw=(raw["_opacity"], raw["_scaling"], raw["_rotation"]),
+                                       dgeom=dg)[0]
+        # the rows the backward pass adds into are cleared, the others left alone
+        seen = got.radii > 0
+        assert bool((dg[seen] == 0).all()) and bool((dg[~seen] == 5.0).all()) and int((~seen).sum()) > 0
         assert torch.equal(o1, o2) and torch.equal(s1, s2) and torch.equal(r1, r2)
         assert got.D == want.D and want.D > 0
         for name in ("geom", "depth", "rect", "ranges", "radii", "n_contrib", "color", "allmap", "final_T"):

@@ -21,7 +21,7 @@ _SIGNATURES = {
     "vings_surfel_project": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float] + [_P] * 14 +
                              [_c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32), _P]),
     "vings_surfel_project_launch": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float] + [_P] * 15),
-    "vings_surfel_project_launch_activate": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float] + [_P] * 18),
+    "vings_surfel_project_launch_activate": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float] + [_P] * 19),
     "vings_surfel_set_tight_binning": (_c.c_int, [_c.c_int]),
     "vings_surfel_project_wait": (_c.c_int, [_c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
     "vings_surfel_bin_low_bits": (_c.c_int, [_c.c_uint32, _c.c_uint32]),
@@ -32,6 +32,7 @@ _SIGNATURES = {
                                     _c.c_uint32] + [_P] * 8 + [_c.c_size_t, _P]),
     "vings_surfel_blend_forward": (_c.c_int, [_c.c_int, _c.c_int] + [_P] * 10),
     "vings_surfel_blend_backward": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int] + [_P] * 11),
+    "vings_surfel_blend_backward_accumulate": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int] + [_P] * 11),
     "vings_surfel_project_backward": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float] +
                                       [_P] * 15),
     "vings_sparse_adam": (_c.c_int, [_P] * 5 + [_c.c_float] * 4 + [_c.c_int, _c.c_int, _P]),

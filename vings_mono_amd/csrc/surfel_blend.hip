@@ -566,7 +566,7 @@ extern "C" int vings_surfel_blend_forward(int H, int W, const uint32_t* ranges,
     return VINGS_OK;
 }
 
-extern "C" int vings_surfel_blend_backward(int N, int H, int W, const uint32_t* ranges,
+static int blend_backward_impl(bool clear, int N, int H, int W, const uint32_t* ranges,
                                            const uint32_t* vals_sorted, const float* geom,
                                            const float* bg, const uint8_t* pixel_mask,
                                            const float* final_T, const uint32_t* n_contrib,
@@ -577,7 +577,8 @@ extern "C" int vings_surfel_blend_backward(int N, int H, int W, const uint32_t* 
     VINGS_REQUIRE(ranges && bg && final_T && n_contrib && dL_dcolor && dL_dallmap && dgeom,
                   "null pointer");
     hipStream_t s = (hipStream_t)stream;
-    VINGS_CHECK_HIP(hipMemsetAsync(dgeom, 0, sizeof(float) * (size_t)N * VINGS_GRAD_STRIDE, s));
+    if (clear)
+        VINGS_CHECK_HIP(hipMemsetAsync(dgeom, 0, sizeof(float) * (size_t)N * VINGS_GRAD_STRIDE, s));
     const int gx = (W + 15) / 16, gy = (H + 15) / 16;
     ProfScope prof(PROF_BLEND_BWD, s);
     blend_bwd_kernel<<<gx * gy, 256, 0, s>>>(H, W, gx, ranges, vals_sorted, geom, bg, pixel_mask,
@@ -606,4 +607,24 @@ extern "C" int vings_surfel_blend_importance(int N, int H, int W, const uint32_t
                                                     reinterpret_cast<uint32_t*>(rgb_max));
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
+}
+
+extern "C" int vings_surfel_blend_backward(int N, int H, int W, const uint32_t* ranges,
+                                           const uint32_t* vals_sorted, const float* geom,
+                                           const float* bg, const uint8_t* pixel_mask,
+                                           const float* final_T, const uint32_t* n_contrib,
+                                           const float* dL_dcolor, const float* dL_dallmap,
+                                           float* dgeom, void* stream) {
+    return blend_backward_impl(true, N, H, W, ranges, vals_sorted, geom, bg, pixel_mask, final_T,
+                               n_contrib, dL_dcolor, dL_dallmap, dgeom, stream);
+}
+
+extern "C" int vings_surfel_blend_backward_accumulate(int N, int H, int W, const uint32_t* ranges,
+                                           const uint32_t* vals_sorted, const float* geom,
+                                           const float* bg, const uint8_t* pixel_mask,
+                                           const float* final_T, const uint32_t* n_contrib,
+                                           const float* dL_dcolor, const float* dL_dallmap,
+                                           float* dgeom, void* stream) {
+    return blend_backward_impl(false, N, H, W, ranges, vals_sorted, geom, bg, pixel_mask, final_T,
+                               n_contrib, dL_dcolor, dL_dallmap, dgeom, stream);
 }

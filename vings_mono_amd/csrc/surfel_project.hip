@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     const float* __restrict__ proj, float* __restrict__ geom, float* __restrict__ depth,
     int32_t* __restrict__ radii, int32_t* __restrict__ rect, uint32_t* __restrict__ tiles_touched,
     uint32_t* __restrict__ block_counts, uint32_t* __restrict__ block_dmin,
-    uint32_t* __restrict__ block_dmax, int tight) {
+    uint32_t* __restrict__ block_dmax, int tight, float* __restrict__ dgeom_clear) {
     __shared__ uint32_t wsum[4], wmin[4], wmax[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     uint32_t touched = 0;
@@ -177,6 +177,11 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
         if (!ok) { touched = 0; x0 = y0 = x1 = y1 = 0; }
         else dlo = dhi = __float_as_uint(dep);
         radii[i] = rad;
+        if (dgeom_clear && rad > 0) {   // the backward pass accumulates into this row
+            float4* z = reinterpret_cast<float4*>(dgeom_clear + (size_t)i * VINGS_GRAD_STRIDE);
+#pragma unroll
+            for (int k = 0; k < VINGS_GRAD_STRIDE / 4; ++k) z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         depth[i] = dep;
         if (ok) {
             float4* g = reinterpret_cast<float4*>(geom + (size_t)i * VINGS_GEOM_STRIDE);
@@ -518,7 +523,8 @@ static int project_launch(int N, int H, int W, float scale_modifier, const float
                           const float* projmatrix, float* geom, float* depth, int32_t* radii,
                           int32_t* rect, uint32_t* tiles_touched, uint32_t* block_prefix,
                           hipStream_t s, int* dev_out, float* act_scales = nullptr,
-                          float* act_rotations = nullptr, float* act_opacities = nullptr) {
+                          float* act_rotations = nullptr, float* act_opacities = nullptr,
+                          float* dgeom_clear = nullptr) {
     VINGS_REQUIRE(N > 0 && H > 0 && W > 0, "sizes");
     VINGS_REQUIRE(means3D && scales && rotations && opacities && colors && viewmatrix &&
                       projmatrix && geom && depth && radii && rect && tiles_touched && block_prefix,
@@ -538,12 +544,12 @@ static int project_launch(int N, int H, int W, float scale_modifier, const float
         project_fwd_kernel<true><<<nb, 256, 0, s>>>(
             N, H, W, scale_modifier, means3D, scales, rotations, opacities, act_scales,
             act_rotations, act_opacities, colors, flow, viewmatrix, projmatrix, geom, depth, radii,
-            rect, tiles_touched, block_prefix, block_prefix + nb + 1, block_prefix + 2 * nb + 1, tight);
+            rect, tiles_touched, block_prefix, block_prefix + nb + 1, block_prefix + 2 * nb + 1, tight, dgeom_clear);
     else
         project_fwd_kernel<false><<<nb, 256, 0, s>>>(
             N, H, W, scale_modifier, means3D, scales, rotations, opacities, nullptr, nullptr,
             nullptr, colors, flow, viewmatrix, projmatrix, geom, depth, radii, rect, tiles_touched,
-            block_prefix, block_prefix + nb + 1, block_prefix + 2 * nb + 1, tight);
+            block_prefix, block_prefix + nb + 1, block_prefix + 2 * nb + 1, tight, nullptr);
     VINGS_LAUNCH_CHECK();
     }
     scan_blocks_kernel<<<1, 1024, 0, s>>>(block_prefix, nb, g_mail[dev]);
@@ -610,8 +616,9 @@ extern "C" int vings_surfel_project_launch_activate(
     const float* raw_rotation, const float* raw_opacity, const float* colors, const float* flow,
     const float* viewmatrix, const float* projmatrix, float* scales, float* rotations,
     float* opacities, float* geom, float* depth, int32_t* radii, int32_t* rect,
-    uint32_t* tiles_touched, uint32_t* block_prefix, void* stream) {
+    uint32_t* tiles_touched, uint32_t* block_prefix, float* dgeom_clear, void* stream) {
     VINGS_REQUIRE(scales && rotations && opacities, "null pointer");
+    VINGS_REQUIRE(((uintptr_t)dgeom_clear & 15) == 0, "dgeom must be 16-byte aligned");
     VINGS_REQUIRE((((uintptr_t)rotations | (uintptr_t)raw_rotation) & 15) == 0 &&
                       (((uintptr_t)scales | (uintptr_t)raw_scaling) & 7) == 0,
                   "rotation arrays must be 16-byte aligned, scaling arrays 8-byte aligned");
@@ -619,7 +626,7 @@ extern "C" int vings_surfel_project_launch_activate(
     return project_launch(N, H, W, scale_modifier, means3D, raw_scaling, raw_rotation, raw_opacity,
                           colors, flow, viewmatrix, projmatrix, geom, depth, radii, rect,
                           tiles_touched, block_prefix, (hipStream_t)stream, &dev, scales, rotations,
-                          opacities);
+                          opacities, dgeom_clear);
 }
 
 extern "C" int vings_surfel_set_tight_binning(int on) {

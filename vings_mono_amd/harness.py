@@ -326,15 +326,17 @@ class SurfelMapper:
         with torch.no_grad():
             # the projection applies the activations itself and fills fb["opac" / "scales" / "rot"]
             xyz, rgb = P["_xyz"].detach(), P["_rgb"].detach()
+            dgeom = torch.empty((max(n, 1), surfel.GRAD_STRIDE), dtype=torch.float32, device=dev)
             st, aux = surfel.rasterize_forward(
                 xyz, rgb, fb["opac"], fb["scales"], fb["rot"], settings,
-                raw=(P["_opacity"].detach(), P["_scaling"].detach(), P["_rotation"].detach()))
+                raw=(P["_opacity"].detach(), P["_scaling"].detach(), P["_rotation"].detach()),
+                dgeom=dgeom)
             loss_vec, d_rgb, d_allmap = mapping_loss_hip(st.color, st.allmap, gt, Rw2c_host, intr,
                                                          self.loss_weights)
             single = reducer is None or reducer.world == 1
             g = fb["grads"]
             view, proj = aux[0], aux[1]
-            dgeom = surfel.blend_backward(st, aux, d_rgb, d_allmap)
+            surfel.blend_backward(st, aux, d_rgb, d_allmap, dgeom=dgeom)
             # per-splat backward + chain rule through the activations + score weighting +
             # bookkeeping in one launch
             _lib.check(L.vings_surfel_project_backward_finish(

@@ -65,13 +65,16 @@ def set_tight_binning(on):
 
 
 def rasterize_forward(means3D, colors, opacities, scales, rotations, settings, keep_keys=False,
-                      raw=None):
+                      raw=None, dgeom=None):
     """Run projection -> binning -> blend. Returns (SurfelForwardState, aux).
 
     `raw` = (raw_opacity, raw_scaling, raw_rotation): the stored parameters.  The projection
     then applies the mapper's activations itself and FILLS opacities / scales / rotations
-    (which only need to be allocated) instead of reading them."""
-    return _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys, True, raw)
+    (which only need to be allocated) instead of reading them.  With `raw`, `dgeom`
+    ([N, GRAD_STRIDE] float32) may be handed over too: the projection zeroes the rows the
+    backward pass will add into, and `blend_backward(..., dgeom=dgeom)` skips its own clearing."""
+    return _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys, True, raw,
+                    dgeom)
 
 
 def view_importance(means3D, colors, opacities, scales, rotations, settings, out=None,
@@ -98,11 +101,14 @@ SPECULATE = os.environ.get("VINGS_SPECULATE", "1") != "0"   # launch sort + blen
 _D_HINT = {}       # (device index, H, W) -> (instance count, depth key bits) of the latest view
 
 
-def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys, blend, raw=None):
+def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys, blend, raw=None,
+             dgeom=None):
     L = _lib.lib()
     dev = means3D.device
     N = means3D.shape[0]
     H, W = int(settings.image_height), int(settings.image_width)
+    if dgeom is not None and raw is None:
+        raise _lib.VingsError("dgeom is cleared by the projection only together with raw=...")
     st = SurfelForwardState()
     st.N, st.H, st.W = N, H, W
     view = _f32c(settings.viewmatrix, "viewmatrix")
@@ -145,7 +151,7 @@ def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys,
             check(L.vings_surfel_project_launch_activate(
                 N, H, W, float(settings.scale_modifier), ptr(means3D), ptr(raw_s), ptr(raw_r),
                 ptr(raw_o), ptr(colors), ptr(flow), ptr(view), ptr(proj), ptr(scales),
-                ptr(rotations), ptr(opacities), *project_args[12:], stream),
+                ptr(rotations), ptr(opacities), *project_args[12:], ptr(dgeom), stream),
                 "vings_surfel_project_launch_activate")
 
     def blend_forward():
@@ -215,13 +221,21 @@ def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys,
     return st, aux
 
 
-def blend_backward(st, aux, g_color, g_allmap):
+def blend_backward(st, aux, g_color, g_allmap, dgeom=None):
     """Pixel half of the backward pass: the per-splat accumulator rows dgeom [N, GRAD_STRIDE]
-    that vings_surfel_project_backward (or its fused _finish form) turns into gradients."""
+    that vings_surfel_project_backward (or its fused _finish form) turns into gradients.
+    `dgeom`: rows already cleared by the forward pass (rasterize_forward(dgeom=...)); the pass
+    then adds into them instead of clearing a fresh array."""
     L = _lib.lib()
     _, _, bg, mask, _ = aux
     N, H, W = st.N, st.H, st.W
     dev = st.geom.device
+    if dgeom is not None:
+        check(L.vings_surfel_blend_backward_accumulate(
+            N, H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg), ptr(mask),
+            ptr(st.final_T), ptr(st.n_contrib), ptr(g_color), ptr(g_allmap), ptr(dgeom),
+            stream_ptr(dev)), "vings_surfel_blend_backward_accumulate")
+        return dgeom
     dgeom = torch.empty((max(N, 1), GRAD_STRIDE), dtype=torch.float32, device=dev)
     check(L.vings_surfel_blend_backward(
         N, H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg), ptr(mask), ptr(st.final_T),
