@@ -32,10 +32,21 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=("auto", "c3", "c4"), default="auto",
+                    help="BASELINE config: c3 = 8-keyframe window + DBA on every GPU (the one the "
+                         "metric is quoted on); c4 = one 32-keyframe window whose keyframes are "
+                         "dealt out over the GPUs (4 per GPU at 8); auto = c4 at 8 GPUs, else c3")
     ap.add_argument("--splats", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--views", type=int, default=8, help="keyframes per GPU per step")
+    ap.add_argument("--views", type=int, default=None,
+                    help="keyframes per GPU per step (default: 8 for c3, 32 / GPUs for c4)")
+    ap.add_argument("--binning", choices=("tight", "reference"), default="tight",
+                    help="tight: a splat enters only the tiles its alpha >= 1/255 footprint "
+                         "reaches (same rendered bits, shorter instance list); reference: the "
+                         "3-sigma square of the reference's rasteriser (bit-exact instance list)")
+    ap.add_argument("--no-side-runs", action="store_true",
+                    help="skip the reference_api / reference_binning figures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dba", action="store_true")
     ap.add_argument("--rehearse-gloo", action="store_true",
@@ -60,16 +71,18 @@ def algorithmic_bytes_blend_bwd(D, P, n_vis, C=9):
 def measured_traffic(splats, W, H):
     """HBM bytes per blend-backward launch from the committed PMC passes of this same
     workload (rocprofv3 cannot run inside the bench); None for any other workload."""
-    path = os.path.join(ROOT, "profiles", "r1", "blend_bwd_hbm_traffic.json")
-    try:
-        with open(path) as f:
-            rec = json.load(f)
-    except OSError:
-        return None
-    wl = rec.get("workload", {})
-    if (wl.get("splats"), wl.get("width"), wl.get("height")) != (splats, W, H):
-        return None
-    return rec.get("hbm_bytes_per_launch")
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "blend_bwd_hbm_traffic.json")),
+                       reverse=True):           # the latest round's passes first
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        wl = rec.get("workload", {})
+        if (wl.get("splats"), wl.get("width"), wl.get("height")) == (splats, W, H):
+            return rec.get("hbm_bytes_per_launch")
+    return None
 
 
 def main():
@@ -95,19 +108,35 @@ def main():
     assert world == args.gpus or world == 1 and args.gpus == 1, \
         f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
-    from vings_mono_amd import harness, synth, parallel, profiling
-    W, H, V = args.width, args.height, args.views
+    from vings_mono_amd import harness, synth, parallel, profiling, surfel
+    workload = args.workload
+    if workload == "auto":
+        workload = "c4" if world == 8 else "c3"
+    W, H = args.width, args.height
     intr = synth.intrinsic_for(W, H)
+    surfel.set_tight_binning(args.binning == "tight")
+    if workload == "c3":
+        # Identical splat replica on every rank, filling the frustum union of ONE V-keyframe
+        # window.  Every rank films that window from its own height (5 cm apart), so all ranks
+        # see the same share of the map: the work per GPU stays what it is at N = 1 (weak
+        # scaling) instead of thinning out as the window would stretch over more keyframes.
+        V = args.views or 8
+        window = V
+        raw = synth.make_splats(args.splats, W, H, n_views=V, seed=synth.SEED_BASE)
+        c2w_rank = synth.window_poses(V)
+        c2w_rank[:, 1, 3] += 0.05 * rank
+    else:
+        # BASELINE config 4: one 32-keyframe window over the whole job, rank r owns keyframes
+        # r*V .. r*V+V-1 of it (4 distinct keyframes per GPU at 8 GPUs); the map fills the
+        # frustum union of all 32.
+        window = 32
+        V = args.views or max(1, window // world)
+        raw = synth.make_splats(args.splats, W, H, n_views=window, seed=synth.SEED_BASE)
+        c2w_rank = synth.window_poses(window)[(rank * V) % window:][:V]
+        assert c2w_rank.shape[0] == V, "views per GPU x GPUs must fit the 32-keyframe window"
     n_views_total = V * world
-    # Identical splat replica on every rank, filling the frustum union of ONE V-keyframe
-    # window.  Every rank films that window from its own height (5 cm apart), so all ranks
-    # see the same share of the map: the work per GPU stays what it is at N = 1 (weak
-    # scaling) instead of thinning out as the window would stretch over more keyframes.
-    raw = synth.make_splats(args.splats, W, H, n_views=V, seed=synth.SEED_BASE)
     mapper = harness.SurfelMapper(raw, dev)
     gt_mapper_params = {k: v.to(dev) for k, v in synth.perturb_splats(raw).items()}
-    c2w_rank = synth.window_poses(V)
-    c2w_rank[:, 1, 3] += 0.05 * rank
     c2w_rank = c2w_rank.to(dev)
     my_views = list(range(rank * V, (rank + 1) * V))      # global keyframe ids
     gts = []
@@ -132,13 +161,13 @@ def main():
     R_host = [w[:3, :3].cpu() for w in w2c_dev]
     cams = [harness.view_settings(w, intr) for w in w2c_dev]
 
-    def step():
+    def step(autograd=args.autograd, torch_loss=args.torch_loss):
         for i, k in enumerate(my_views):
-            if args.autograd or args.torch_loss:
+            if autograd or torch_loss:
                 # the reference's formulation: PyTorch activations / autograd / bookkeeping
                 # around the rasteriser (and, with --torch-loss, the PyTorch loss graph)
                 radii, cur = mapper.backward_view(w2c_dev[i], intr, gts[i], Rw2c_host=R_host[i],
-                                                  torch_loss=args.torch_loss)
+                                                  torch_loss=torch_loss)
                 mapper.finish_view(radii, cur, k, reducer)
             else:
                 mapper.fused_view(cams[i], intr, gts[i], R_host[i], k, reducer)
@@ -183,9 +212,31 @@ def main():
 
     frames = n_views_total * args.steps
     value = frames / elapsed
+    stats = mapper.last_stats()
+
+    def side_run(n_steps=2, **kw):
+        """frames/s of a variant of the step, a few steps inside this same invocation."""
+        step(**kw)
+        barrier()
+        t = time.perf_counter()
+        for _ in range(n_steps):
+            step(**kw)
+        barrier()
+        return round(n_views_total * n_steps / (time.perf_counter() - t), 3)
+
+    reference_api = reference_binning = None
+    if world == 1 and not args.no_side_runs and not (args.autograd or args.torch_loss):
+        # the reference's own call pattern (gaussian_base.py:367-403): PyTorch activations,
+        # GaussianRasterizer through autograd, the PyTorch loss graph, loss.backward(), PyTorch
+        # score bookkeeping, SparseGaussianAdam.step -- through the drop-in names
+        reference_api = side_run(autograd=True, torch_loss=True)
+        if args.binning == "tight":
+            surfel.set_tight_binning(False)
+            reference_binning = side_run()
+            reference_binning_D = mapper.last_stats()["D"]
+            surfel.set_tight_binning(True)
 
     # ---- roofline of the dominant kernel (blend backward), measured with HIP events ----
-    stats = mapper.last_stats()
     roof = None
     if "blend_bwd" in prof and prof["blend_bwd"]["count"] > 0:
         avg_ms = prof["blend_bwd"]["ms"] / prof["blend_bwd"]["count"]
@@ -195,10 +246,11 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": measured_traffic(args.splats, W, H), "avg_kernel_ms": round(avg_ms, 4),
                 "algorithmic_bytes": int(alg),
-                "note": "bound by vector-instruction issue, not by HBM: about 1.0e9 wave "
-                        "instructions per launch on 1024 SIMDs at the 2.6 (plain) to 12 (lane "
-                        "swap) cycles each costs on gfx950 (profiles/r1/valu_rate.txt, "
-                        "profiles/r1/blend_sq_counters.txt)"}
+                "note": "achieved / avg_kernel_ms are measured in this run (HIP events on the "
+                        "launch stream); traffic is NOT: it is the FETCH_SIZE / WRITE_SIZE "
+                        "figure of the committed rocprofv3 PMC passes of this same workload "
+                        "(profiles/, null for any other workload).  The kernel is bound by "
+                        "vector-instruction issue, not by HBM (profiles/*/blend_sq_counters.txt)"}
     stage_ms = {k: round(v["ms"] / max(v["count"], 1), 4) for k, v in prof_all.items()}
     if roof is not None:
         stage_ms["blend_bwd"] = roof["avg_kernel_ms"]     # the timed region's own figure
@@ -216,13 +268,26 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" + (" (gloo rehearsal on one GPU: not a benchmark result)" if args.rehearse_gloo else ""),
-            "config": {"workload": "BASELINE config 3: 1.0M splats, 8-keyframe window 1920x1080 "
-                                   "+ DBA step per GPU",
+            "config": {"workload": ("BASELINE config %s: %.1fM splats, %s %dx%d%s" % (
+                                        workload[1], args.splats / 1e6,
+                                        ("%d-keyframe window per GPU" % V) if workload == "c3" else
+                                        ("one %d-keyframe window, %d keyframes per GPU" % (window, V)),
+                                        W, H, "" if dba is None else " + DBA step per GPU")),
+                       "binning": args.binning,
+                       "view_step": "autograd" if (args.autograd or args.torch_loss) else "fused C-ABI sequence",
+                       "loss": "torch graph" if args.torch_loss else "fused HIP kernels",
                        "splats": args.splats, "width": W, "height": H, "views_per_gpu": V,
                        "dba": None if dba is None else dba.describe(),
                        "instances_D": stats["D"], "visible": stats["n_vis"],
                        "parallelism": f"views sharded over {world} GPU(s), grad all-reduce"},
             "roofline": roof, "cpu_baseline": cpu, "stage_ms": stage_ms,
+            "reference_api": None if reference_api is None else {
+                "value": reference_api, "unit": "frames/s",
+                "what": "same step through GaussianRasterizer autograd + PyTorch loss graph + "
+                        "PyTorch bookkeeping (the reference's call pattern, gaussian_base.py:367-403)"},
+            "reference_binning": None if reference_binning is None else {
+                "value": reference_binning, "unit": "frames/s", "instances_D": reference_binning_D,
+                "what": "fused step with the reference's 3-sigma tile squares (bit-exact instance list)"},
             "loss": None if mapper.last_loss is None else round(float(mapper.last_loss), 6),
         }
         print(json.dumps(out))

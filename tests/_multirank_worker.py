@@ -16,13 +16,19 @@ def main():
     dist.init_process_group("gloo")
     from vings_mono_amd import harness, parallel, synth
     dev = torch.device("cuda:0")
-    W, H, n, steps = 160, 96, 5000, 2
+    W, H, n, steps = 160, 96, 5000, 3
     raw = synth.make_splats(n, W, H, n_views=world * steps, seed=33)
     intr = synth.intrinsic_for(W, H)
     c2w = synth.window_poses(world * steps)
     gtp = {k: v.to(dev) for k, v in synth.perturb_splats(raw).items()}
+    from vings_mono_amd import maintenance
     a, b = harness.SurfelMapper(raw, dev), harness.SurfelMapper(raw, dev)
+    # c = b, except that it merges its record keys over the ranks BEFORE the map maintenance
+    # below; b carries its unmerged keys through the prune and the append
+    c = harness.SurfelMapper(raw, dev)
     red = parallel.GradReducer(n, dev, world)
+    red_c = parallel.GradReducer(n, dev, world)
+    extra = {k: v[:300].clone() for k, v in synth.make_splats(600, W, H, n_views=2, seed=34).items()}
     for s in range(steps):
         k = s * world + rank                      # this rank's keyframe of the step
         w2c = torch.linalg.inv(c2w[k]).to(dev)
@@ -33,21 +39,33 @@ def main():
         radii, cur = a.backward_view(w2c, intr, gt)
         a.finish_view(radii, cur, k, red)
         b.fused_view(harness.view_settings(w2c, intr), intr, gt, w2c[:3, :3].cpu(), k, red)
+        c.fused_view(harness.view_settings(w2c, intr), intr, gt, w2c[:3, :3].cpu(), k, red_c)
         if s == 0:
             a.sync_records(red)                    # blocking form after the first step ...
             b.sync_records(red)
-    for m in (a, b):                               # ... and the overlapped form at the end
-        fin = m.sync_records(red, async_op=True)
+            c.sync_records(red_c)
+        if s == 1:
+            # map maintenance between two view steps of a multi-rank job: every rank prunes the
+            # same splats and appends the same new ones (the splat count changes twice)
+            c.sync_records(red_c)
+            for m in (a, b, c):
+                mask = (torch.arange(m.n, device=dev) % 9) == 4
+                maintenance.prune(m, mask)
+                maintenance.add_splats(m, extra)
+                assert m.n == n - int(mask.sum()) + 300
+    for m, r in ((a, red), (b, red), (c, red_c)):  # ... and the overlapped form at the end
+        fin = m.sync_records(r, async_op=True)
         fin()
     torch.cuda.synchronize()
     state = {"rank": rank}
-    for name, m in (("autograd", a), ("fused", b)):
+    for name, m in (("autograd", a), ("fused", b), ("fused_synced_first", c)):
         state[name] = {k: m.params[k].detach().cpu() for k in m.NAMES}
         state[name]["global_scores"] = m.global_scores.cpu()
         state[name]["local_scores"] = m.local_scores.cpu()
         state[name]["kf_id"] = m.globalkf_id.cpu()
         state[name]["kf_max"] = m.globalkf_max_scores.cpu()
-    state["raw"] = {k: raw[k].clone() for k in a.NAMES}
+    keep = (torch.arange(n) % 9) != 4
+    state["raw"] = {k: torch.cat((raw[k][keep], extra[k])) for k in a.NAMES}
     torch.save(state, f"{out_path}.rank{rank}.pt")
     dist.barrier()
     dist.destroy_process_group()

@@ -63,6 +63,9 @@ def test_checkpoint_uses_reference_names_and_round_trips(tmp_path):
     assert sorted(d) == sorted(["_xyz", "_rgb", "_scaling", "_rotation", "_opacity", "_global_scores",
                                 "_local_scores", "_stable_mask", "_globalkf_id", "_globalkf_max_scores"])
     assert d["_stable_mask"].dtype == torch.bool and d["_globalkf_id"].dtype == torch.int64
+    # the parameter entries are trainable leaves, as the reference's load_pt_ckpt expects
+    for k in m.NAMES:
+        assert isinstance(d[k], torch.nn.Parameter) and d[k].requires_grad
     m2 = io_formats.load_pt_ckpt(path, "cpu")
     for k in m.NAMES:
         assert torch.equal(m2.params[k].detach(), m.params[k].detach())

@@ -86,6 +86,12 @@ def test_loss_and_gradients_tile_aligned():
     _check(64, 96, 5)
 
 
+def test_loss_and_gradients_full_hd():
+    # the shape bench.py runs: 1920x1080 (8 160 SSIM tiles, 32x8 geometry tiles, 135 rows of
+    # per-block partial sums)
+    _check(1080, 1920, 17)
+
+
 def test_loss_and_gradients_tiny_image():
     _check(5, 7, 11)            # smaller than the SSIM window: padding everywhere
 

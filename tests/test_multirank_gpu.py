@@ -31,9 +31,15 @@ def test_two_rank_view_steps(tmp_path):
     s0 = torch.load(out + ".rank0.pt", weights_only=True)
     s1 = torch.load(out + ".rank1.pt", weights_only=True)
     names = ("_xyz", "_rgb", "_opacity", "_scaling", "_rotation")
-    for impl in ("autograd", "fused"):
+    for impl in ("autograd", "fused", "fused_synced_first"):
         for k in names + ("global_scores", "local_scores", "kf_id", "kf_max"):
             assert torch.equal(s0[impl][k], s1[impl][k]), f"{impl}: replicas differ in {k}"
+    # Between the second and the third step every mapper was pruned and extended.  The record
+    # keys a rank had not yet merged travelled with their splats: the mapper that merged them
+    # before the maintenance ends with the same records and parameters, bit for bit.
+    for k in names + ("global_scores", "local_scores", "kf_id", "kf_max"):
+        assert torch.equal(s0["fused"][k], s0["fused_synced_first"][k]), k
+    assert s0["fused"]["_xyz"].shape[0] == 5000 - len(range(4, 5000, 9)) + 300
     for k in names:
         ua = s0["autograd"][k] - s0["raw"][k]
         ub = s0["fused"][k] - s0["raw"][k]

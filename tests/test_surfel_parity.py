@@ -95,6 +95,7 @@ CASES = [
     dict(n=3000, W=200, H=120, scale_mul=0.05),        # sub-pixel splats: low-pass branch
     dict(n=1, W=64, H=48),
     dict(n=200000, W=1920, H=1080),                    # BASELINE config 2
+    dict(n=1000000, W=1920, H=1080, n_views=8, view_k=3),   # one view of BASELINE config 3
 ]
 
 
@@ -196,6 +197,7 @@ BWD_CASES = [
     dict(n=6000, W=200, H=120, scale_mul=3.0),
     dict(n=3000, W=200, H=120, scale_mul=0.05),
     dict(n=200000, W=1920, H=1080),                    # BASELINE config 2
+    dict(n=1000000, W=1920, H=1080, n_views=8, view_k=3),   # one view of BASELINE config 3
 ]
 
 

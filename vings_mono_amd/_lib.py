@@ -85,10 +85,13 @@ def lib():
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` or `make -C vings_mono_amd/csrc` (hipcc, gfx950)")
         handle = ctypes.CDLL(LIB_PATH)
+        missing = [name for name in _SIGNATURES if not hasattr(handle, name)]
+        if missing:
+            # a stale build: fail here, by name, not later with an AttributeError
+            raise VingsError(f"{LIB_PATH} does not export {', '.join(sorted(missing))}: "
+                             "rebuild it (`make -C vings_mono_amd/csrc`)")
         for name, (res, args) in _SIGNATURES.items():
-            fn = getattr(handle, name, None)
-            if fn is None:
-                continue  # optional groups are bound by their own modules
+            fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
         _lib = handle
@@ -96,7 +99,11 @@ def lib():
 
 
 def bind(name, restype, argtypes):
-    fn = getattr(lib(), name)
+    """Signature of an entry point that a module other than this one binds (dba.py)."""
+    fn = getattr(lib(), name, None)
+    if fn is None:
+        raise VingsError(f"{LIB_PATH} does not export {name}: rebuild it "
+                         "(`make -C vings_mono_amd/csrc`)")
     fn.restype = restype
     fn.argtypes = argtypes
     return fn

@@ -70,7 +70,8 @@ class _Problem:
 
     _ws_cache = {}
 
-    def __init__(self, poses, disps, intr, disps_sens, target, weight, eta, ii, jj, t0, t1):
+    def __init__(self, poses, disps, intr, disps_sens, target, weight, eta, ii, jj, t0, t1,
+                 private_ws=False):
         self.poses = _gpu_f32(poses, "poses", inplace=True)
         self.disps = _gpu_f32(disps, "disps", inplace=True)
         dev = self.poses.device
@@ -98,8 +99,13 @@ class _Problem:
                                             ctypes.byref(lay)), "vings_dba_layout_query")
         self.lay = lay
         key = (dev.index, int(lay.total_bytes))
-        ws = _Problem._ws_cache.get(key)
-        if ws is None:
+        # ba() is done with its workspace when it returns, so calls of one size share a cached
+        # one; a BACore keeps its linearised system there between init / hessian / retract and
+        # owns its workspace like the reference's BACore owns its state
+        ws = None if private_ws else _Problem._ws_cache.get(key)
+        if private_ws:
+            ws = torch.empty(int(lay.total_bytes) + 256, dtype=torch.uint8, device=dev)
+        elif ws is None:
             ws = torch.empty(int(lay.total_bytes) + 256, dtype=torch.uint8, device=dev)
             if len(_Problem._ws_cache) > 8:
                 _Problem._ws_cache.clear()
@@ -154,7 +160,8 @@ class BACore:
 
     def init(self, poses, disps, intrinsics, disps_sens, target, weight, eta, ii, jj, t0, t1,
              itrs, lm, ep, motion_only):
-        self.pr = _Problem(poses, disps, intrinsics, disps_sens, target, weight, eta, ii, jj, t0, t1)
+        self.pr = _Problem(poses, disps, intrinsics, disps_sens, target, weight, eta, ii, jj, t0, t1,
+                           private_ws=True)
         self.motion_only = bool(motion_only)
         self._linearize()
 

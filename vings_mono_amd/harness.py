@@ -240,6 +240,7 @@ class SurfelMapper:
         gaussian_model.py:163-168).  With one rank this is exactly the reference order:
         record the scores, weight every gradient by s0 / (S0 + 1e-6 + s0) using the updated
         global score, zero the radii of stable splats, step."""
+        self._match_reducer(reducer)
         s0 = cur[:, 0]
         g0_local = (self.global_scores[:, 0] + s0).clamp(0.0, 1e4)
         w = (s0 / (g0_local + 1e-6 + s0)).unsqueeze(1)
@@ -266,6 +267,19 @@ class SurfelMapper:
         self._last_radii = radii
 
     # ------------------------------------------------------------------ multi-GPU records
+    def _match_reducer(self, reducer):
+        """Map maintenance (prune, add_splats) changes the splat count between view steps; the
+        exchange buffer and the pending record keys must follow, or the packing kernels index
+        them with the wrong N."""
+        if reducer is not None and reducer.world > 1 and reducer.n != self.n:
+            reducer.resize(self.n)
+        pending = getattr(self, "_pending_keys", None)
+        if pending is not None and pending.shape[0] != self.n:
+            from . import _lib
+            raise _lib.VingsError(
+                f"pending record keys hold {pending.shape[0]} rows for {self.n} splats: change the "
+                "splat count through maintenance.prune / add_splats, which carry them along")
+
     def _record_keys(self):
         """Running maximum of this rank's (best score | keyframe, error score) keys since the
         last sync_records; int64 [N,2]."""
@@ -319,6 +333,7 @@ class SurfelMapper:
         `settings` is the view's GaussianRasterizationSettings (see `view_settings`)."""
         from . import _lib, surfel
         L = _lib.lib()
+        self._match_reducer(reducer)
         fb = self._fused_buffers()
         P, n, dev = self.params, self.n, self.device
         stream = _lib.stream_ptr(dev)

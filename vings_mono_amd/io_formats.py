@@ -95,9 +95,20 @@ def load_ply(path):
             "_rotation": take(numbered("rot"))}
 
 
-def save_pt_ckpt(mapper, path):
-    """The reference's checkpoint dict from a harness.SurfelMapper."""
-    d = {k: mapper.params[k].detach() for k in NAMES}
+def save_pt_ckpt(mapper, path, reducer=None):
+    """The reference's checkpoint dict from a harness.SurfelMapper.  The five parameter entries
+    are nn.Parameters like the reference's own (gaussian_base.py:492-505): its load_pt_ckpt
+    assigns them straight to the model and builds the optimiser on them, so plain tensors would
+    load with requires_grad=False and could not be trained further.  On a multi-rank job pass
+    the job's GradReducer: the score records of a rank are complete only after the record keys
+    have been merged over the ranks."""
+    if getattr(mapper, "_pending_keys", None) is not None:
+        if reducer is None or reducer.world == 1:
+            raise ValueError("this mapper holds record keys not yet merged over the ranks: "
+                             "pass the job's GradReducer (or call sync_records first)")
+        mapper.sync_records(reducer)
+        mapper._pending_keys = None
+    d = {k: torch.nn.Parameter(mapper.params[k].detach().clone()) for k in NAMES}
     d.update({ref: getattr(mapper, ours) for ref, ours in RECORDS.items()})
     torch.save(d, path)
 

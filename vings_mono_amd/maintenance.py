@@ -69,6 +69,10 @@ def prune(mapper, prune_mask):
             arrays.append(st["exp_avg_sq"]); slots.append(("exp_avg_sq", k))
     for attr in ("global_scores", "local_scores", "stable_mask", "globalkf_id", "globalkf_max_scores"):
         arrays.append(getattr(mapper, attr)); slots.append(("record", attr))
+    # multi-GPU jobs: the record maxima not yet merged over the ranks travel with their splats
+    pending = getattr(mapper, "_pending_keys", None)
+    if pending is not None:
+        arrays.append(pending); slots.append(("pending", "keys"))
     outs, m = compact(arrays, ~prune_mask.reshape(-1).bool())
     new = dict(zip(slots, outs))
     for group in mapper.optimizer.param_groups:
@@ -84,6 +88,8 @@ def prune(mapper, prune_mask):
             mapper.optimizer.state[p] = state
     for attr in ("global_scores", "local_scores", "stable_mask", "globalkf_id", "globalkf_max_scores"):
         setattr(mapper, attr, new[("record", attr)])
+    if pending is not None:
+        mapper._pending_keys = new[("pending", "keys")]
     mapper.n = m
     mapper._fb = None          # buffers of the fused view step are sized per splat count
     return m
@@ -159,7 +165,9 @@ def keyframe_pointcloud(c2w, intr, gt_rgb, gt_depth, pred_accum, n_points, accum
     else:
         n_open = int((valid & ~(pred_accum.reshape(H, W) > accum_thresh)).sum())
     n = 0 if n_all == 0 else min(int(n_open / n_all * n_points), n_all)
-    valid_ids = torch.nonzero(depth.reshape(-1)).squeeze(1)            # row-major, int64
+    # the pool is the population n_all counts: depth > 0 (gaussian_utils.py:32,46), which also
+    # keeps negative and NaN depths out of the back-projection
+    valid_ids = torch.nonzero(valid.reshape(-1)).squeeze(1)            # row-major, int64
     if perm is None:
         perm = torch.randperm(valid_ids.shape[0], device=dev)
     picked = valid_ids[perm.to(dev)[:n]].contiguous()
@@ -268,6 +276,8 @@ def add_splats(mapper, new_params):
     mapper.stable_mask = torch.cat((mapper.stable_mask, z(k, dt=torch.bool)))
     mapper.globalkf_id = torch.cat((mapper.globalkf_id, z(k, dt=torch.int64)))
     mapper.globalkf_max_scores = torch.cat((mapper.globalkf_max_scores, z(k, dt=torch.float32)))
+    if getattr(mapper, "_pending_keys", None) is not None:
+        mapper._pending_keys = torch.cat((mapper._pending_keys, z(k, 2, dt=torch.int64)))
     mapper.n += k
     mapper._fb = None
     return mapper.n

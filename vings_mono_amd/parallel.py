@@ -54,6 +54,15 @@ class GradReducer:
         if world > 1:
             self.fbuf = torch.zeros((PACK_WIDTH, n), dtype=torch.float32, device=device)
 
+    def resize(self, n):
+        """The splat count changed (pruning, new keyframe): a fresh exchange buffer.  Nothing
+        of the old one is kept; it only lives from the pack to the unpack of one view."""
+        if n != self.n:
+            self.n = n
+            if self.world > 1:
+                self.fbuf = torch.zeros((PACK_WIDTH, n), dtype=torch.float32,
+                                        device=self.fbuf.device)
+
     class _Done:
         """Handle of a collective that has already completed."""
         def wait(self):
