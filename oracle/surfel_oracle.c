@@ -479,13 +479,25 @@ int surfel_blend_backward(int H, int W, const uint32_t* ranges, const uint32_t* 
                         real dlx = dpy * h.kz - dpz * h.ky;
                         real dly = dpz * h.kx - dpx * h.kz;
                         real dlz = dpx * h.ky - dpy * h.kx;
-                        real fx = (real)x, fy = (real)y;
+                        /* Gradient w.r.t. the rows of T' = M T, M = [[1,0,-cx],[0,1,-cy],[0,0,1]]:
+                         * the homography in pixel coordinates centred on the splat (cx, cy).
+                         * k = (x-cx) Tw - Tu' and l = (y-cy) Tw - Tv' are the same vectors, so
+                         * dL/dTw' = (x-cx) dk + (y-cy) dl + ...: pixel offsets of a few pixels
+                         * instead of absolute coordinates of up to the image size, whose
+                         * products cancel down to 1e-3 of their size in the chain rule that
+                         * follows (surfel_project_backward applies M to the projection). */
+                        /* (cx, cy) clamped into the image: any fixed point serves, and a
+                         * centre far outside the image (a splat crossing the camera plane)
+                         * would bring back offsets of 1e5 pixels */
+                        real ccx = rmin(rmax(xy[2 * g], 0), (real)(W - 1));
+                        real ccy = rmin(rmax(xy[2 * g + 1], 0), (real)(H - 1));
+                        real ex = (real)x - ccx, ey = (real)y - ccy;
                         real* o = dL_dtransmat + 9 * g;
                         atomic_add(o + 0, -dkx); atomic_add(o + 1, -dky); atomic_add(o + 2, -dkz);
                         atomic_add(o + 3, -dlx); atomic_add(o + 4, -dly); atomic_add(o + 5, -dlz);
-                        atomic_add(o + 6, fx * dkx + fy * dlx + dL_dz * h.sx);
-                        atomic_add(o + 7, fx * dky + fy * dly + dL_dz * h.sy);
-                        atomic_add(o + 8, fx * dkz + fy * dlz + dL_dz);
+                        atomic_add(o + 6, ex * dkx + ey * dlx + dL_dz * h.sx);
+                        atomic_add(o + 7, ex * dky + ey * dly + dL_dz * h.sy);
+                        atomic_add(o + 8, ex * dkz + ey * dlz + dL_dz);
                     } else {
                         real dG_dx = -h.G * FILTER_INV_SQUARE * h.dx;
                         real dG_dy = -h.G * FILTER_INV_SQUARE * h.dy;
@@ -536,32 +548,55 @@ int surfel_project_backward(int N, int H, int W, real scale_mod, const real* mea
         real cosv = -(pv[0] * n[0] + pv[1] * n[1] + pv[2] * n[2]);
         real mult = cosv > 0 ? (real)1 : (real)-1;
 
-        real dA[3][3];
+        /* dL_dtransmat holds the gradient w.r.t. T' = M T (pixel coordinates centred on the
+         * splat, see surfel_blend_backward); T' = (M B) X with X = [L0 L1 p; 0 0 1], so the
+         * chain rule uses the centred projection Bc = M B, formed from the projection matrix
+         * itself: Bc[0] = (W/2) P0 + ((W-1)/2 - cx) P3, never B[0] - cx B[2]. */
+        real dA[3][3], dAx[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
         for (int r = 0; r < 3; ++r)
             for (int c = 0; c < 3; ++c) dA[r][c] = dL_dtransmat[9 * i + 3 * r + c];
-        /* gradient through the bounding-box centre (low-pass-filter branch) */
-        real gx_ = dL_dxy[2 * i], gy_ = dL_dxy[2 * i + 1];
-        if (gx_ != 0 || gy_ != 0) {
+        real cx, cy;
+        {
             const real t[3] = {9, 9, -1};
             const real *Tu = A[0], *Tv = A[1], *Tw = A[2];
             real d = t[0] * Tw[0] * Tw[0] + t[1] * Tw[1] * Tw[1] + t[2] * Tw[2] * Tw[2];
             real inv = (real)1 / d;
             real f[3] = {inv * t[0], inv * t[1], inv * t[2]};
-            real cx = f[0] * Tu[0] * Tw[0] + f[1] * Tu[1] * Tw[1] + f[2] * Tu[2] * Tw[2];
-            real cy = f[0] * Tv[0] * Tw[0] + f[1] * Tv[1] * Tw[1] + f[2] * Tv[2] * Tw[2];
-            for (int k = 0; k < 3; ++k) {
-                dA[0][k] += gx_ * f[k] * Tw[k];
-                dA[1][k] += gy_ * f[k] * Tw[k];
-                dA[2][k] += gx_ * (f[k] * Tu[k] - 2 * cx * f[k] * Tw[k]) +
-                            gy_ * (f[k] * Tv[k] - 2 * cy * f[k] * Tw[k]);
+            cx = f[0] * Tu[0] * Tw[0] + f[1] * Tu[1] * Tw[1] + f[2] * Tu[2] * Tw[2];
+            cy = f[0] * Tv[0] * Tw[0] + f[1] * Tv[1] * Tw[1] + f[2] * Tv[2] * Tw[2];
+            /* gradient through the bounding-box centre (low-pass-filter branch), w.r.t. T */
+            real gx_ = dL_dxy[2 * i], gy_ = dL_dxy[2 * i + 1];
+            if (gx_ != 0 || gy_ != 0) {
+                for (int k = 0; k < 3; ++k) {
+                    dAx[0][k] = gx_ * f[k] * Tw[k];
+                    dAx[1][k] = gy_ * f[k] * Tw[k];
+                    dAx[2][k] = gx_ * (f[k] * Tu[k] - 2 * cx * f[k] * Tw[k]) +
+                                gy_ * (f[k] * Tv[k] - 2 * cy * f[k] * Tw[k]);
+                }
+            }
+        }
+        /* the point the blend pass centred on: (cx, cy) clamped into the image */
+        const real ccx = rmin(rmax(cx, 0), (real)(W - 1)), ccy = rmin(rmax(cy, 0), (real)(H - 1));
+        real Bc[3][4];
+        {
+            const real hw = (real)W / 2, hh = (real)H / 2;
+            const real ow = (real)(W - 1) / 2, oh = (real)(H - 1) / 2;
+            for (int c = 0; c < 4; ++c) {
+                real p0 = proj[c * 4 + 0], p1 = proj[c * 4 + 1], p3 = proj[c * 4 + 3];
+                Bc[0][c] = hw * p0 + (ow - ccx) * p3;
+                Bc[1][c] = hh * p1 + (oh - ccy) * p3;
+                Bc[2][c] = p3;
             }
         }
         /* A[:,0] = B3*L0, A[:,1] = B3*L1, A[:,2] = B3*p + b */
         real dL0[3], dL1[3], dp[3];
         for (int k = 0; k < 3; ++k) {
-            dL0[k] = B[0][k] * dA[0][0] + B[1][k] * dA[1][0] + B[2][k] * dA[2][0];
-            dL1[k] = B[0][k] * dA[0][1] + B[1][k] * dA[1][1] + B[2][k] * dA[2][1];
-            dp[k] = B[0][k] * dA[0][2] + B[1][k] * dA[1][2] + B[2][k] * dA[2][2];
+            dL0[k] = (Bc[0][k] * dA[0][0] + Bc[1][k] * dA[1][0] + Bc[2][k] * dA[2][0]) +
+                     (B[0][k] * dAx[0][0] + B[1][k] * dAx[1][0] + B[2][k] * dAx[2][0]);
+            dL1[k] = (Bc[0][k] * dA[0][1] + Bc[1][k] * dA[1][1] + Bc[2][k] * dA[2][1]) +
+                     (B[0][k] * dAx[0][1] + B[1][k] * dAx[1][1] + B[2][k] * dAx[2][1]);
+            dp[k] = (Bc[0][k] * dA[0][2] + Bc[1][k] * dA[1][2] + Bc[2][k] * dA[2][2]) +
+                    (B[0][k] * dAx[0][2] + B[1][k] * dAx[1][2] + B[2][k] * dAx[2][2]);
         }
         /* n = mult * V3 * R[:,2]  ->  dR[:,2] = mult * V3^T dn */
         real dn[3] = {mult * dL_dnormal[3 * i], mult * dL_dnormal[3 * i + 1], mult * dL_dnormal[3 * i + 2]};
