@@ -310,6 +310,19 @@ int vings_splat_compact_apply(int N, const int32_t* dst_index, int n_arrays,
                               const void* const* src_host, void* const* dst_host,
                               const int* row_bytes_host, void* stream);
 
+/* The plan step for callers that cannot allocate (code under HIP graph capture, serving loops,
+ * harnesses that forbid hipMalloc): no workspace argument, no host read-back, no
+ * synchronisation.  It has no counterpart in the reference.  The per-block counts live in a
+ * static device array of the library (128 KiB per GPU, held until the process ends), so N is
+ * limited to vings_splat_compact_static_max_rows() = 8 388 608; a larger N is rejected with
+ * VINGS_ERR_ARG.  The number of kept rows is written to the DEVICE word n_keep_device on the
+ * stream.  dst_index is what vings_splat_compact_plan produces.  All calls on one GPU share
+ * that GPU's scratch array: calls that overlap in time on one GPU (two streams, two threads)
+ * race; calls on one stream do not. */
+int vings_splat_compact_static_max_rows(void);
+int vings_splat_compact_plan_static(int N, const uint8_t* keep, int32_t* dst_index,
+                                    int64_t* n_keep_device, void* stream);
+
 /* ------------------------------------------------------------------------
  * mean_dist2[i] = mean of the squared distances from point i to its three nearest other
  * points; xyz[N,3].  Serves distCUDA2 (gaussian_utils.py:12-16; callers gaussian_model.py:72,

@@ -48,6 +48,8 @@ _SIGNATURES = {
     "vings_splat_compact_plan": (_c.c_int, [_c.c_int, _P, _P, _P, _c.c_size_t,
                                             _c.POINTER(_c.c_int64), _P]),
     "vings_splat_compact_apply": (_c.c_int, [_c.c_int, _P, _c.c_int, _P, _P, _P, _P]),
+    "vings_splat_compact_static_max_rows": (_c.c_int, []),
+    "vings_splat_compact_plan_static": (_c.c_int, [_c.c_int, _P, _P, _P, _P]),
     "vings_knn3_mean_dist2": (_c.c_int, [_c.c_int, _P, _P, _P]),
     "vings_keyframe_backproject": (_c.c_int, [_c.c_int] * 3 + [_P] * 3 + [_c.POINTER(_c.c_float)] +
                                    [_c.c_float] * 4 + [_P] * 3),

@@ -7,9 +7,19 @@
 //   update_records(mode="prune")  /root/reference/scripts/gaussian/gaussian_model.py:178-183
 // (called from add_new_frame :121-123 and storage_control :246-248): 20 index_select-style
 // launches plus 20 mask scans there.
+#include <mutex>
+
 #include "common.hpp"
 
 namespace vings {
+
+// Scratch of vings_splat_compact_plan_static: the per-block counts of the largest mask it
+// accepts, in the library's own device memory (every GPU the library runs on holds one copy at
+// its own address for the life of the process).  In host code this name is only a handle for
+// hipGetSymbolAddress; kernels receive the address that call returns.
+constexpr int kStaticMaxRows = 1 << 23;                       // 8 388 608 splats
+constexpr int kStaticMaxBlocks = kStaticMaxRows / 256;        // 32 768 blocks -> 128 KiB + 4 B
+static __device__ __align__(256) uint32_t g_compact_scratch[kStaticMaxBlocks + 1];
 
 // keep[i] != 0 -> dst[i] = number of kept rows before i.  Block counts, a single-workgroup
 // scan over them, then the per-row offsets.
@@ -24,7 +34,8 @@ __global__ __launch_bounds__(256) void compact_count_kernel(int N, const uint8_t
     if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-__global__ __launch_bounds__(1024) void compact_scan_kernel(uint32_t* __restrict__ counts, int nb) {
+__global__ __launch_bounds__(1024) void compact_scan_kernel(uint32_t* __restrict__ counts, int nb,
+                                                            long long* __restrict__ total_out) {
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
     if (threadIdx.x == 0) carry_s = 0;
@@ -44,7 +55,10 @@ __global__ __launch_bounds__(1024) void compact_scan_kernel(uint32_t* __restrict
         if (threadIdx.x == 1023) carry_s = carry + woff + inc;
         __syncthreads();
     }
-    if (threadIdx.x == 0) counts[nb] = carry_s;
+    if (threadIdx.x == 0) {
+        counts[nb] = carry_s;
+        if (total_out) *total_out = (long long)carry_s;
+    }
 }
 
 __global__ __launch_bounds__(256) void compact_index_kernel(int N, const uint8_t* __restrict__ keep,
@@ -113,7 +127,7 @@ extern "C" int vings_splat_compact_plan(int N, const uint8_t* keep, int32_t* dst
     const int nb = cdiv(N, 256);
     compact_count_kernel<<<nb, 256, 0, s>>>(N, keep, counts);
     VINGS_LAUNCH_CHECK();
-    compact_scan_kernel<<<1, 1024, 0, s>>>(counts, nb);
+    compact_scan_kernel<<<1, 1024, 0, s>>>(counts, nb, nullptr);
     VINGS_LAUNCH_CHECK();
     compact_index_kernel<<<nb, 256, 0, s>>>(N, keep, counts, dst_index);
     VINGS_LAUNCH_CHECK();
@@ -121,6 +135,53 @@ extern "C" int vings_splat_compact_plan(int N, const uint8_t* keep, int32_t* dst
     VINGS_CHECK_HIP(hipMemcpyAsync(&total, counts + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     VINGS_CHECK_HIP(hipStreamSynchronize(s));
     *n_keep_host = (int64_t)total;
+    return VINGS_OK;
+}
+
+namespace {
+constexpr int kMaxDev = 64;
+std::mutex g_scratch_mu;
+uint32_t* g_scratch_ptr[kMaxDev] = {};
+}  // namespace
+
+extern "C" int vings_splat_compact_static_max_rows(void) { return kStaticMaxRows; }
+
+extern "C" int vings_splat_compact_plan_static(int N, const uint8_t* keep, int32_t* dst_index,
+                                               int64_t* n_keep_device, void* stream) {
+    VINGS_REQUIRE(N >= 0, "sizes");
+    VINGS_REQUIRE(N <= kStaticMaxRows,
+                  "more rows than the library's static scratch holds (vings_splat_compact_static_max_rows): "
+                  "use vings_splat_compact_plan with a workspace");
+    VINGS_REQUIRE(n_keep_device, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    int dev = 0;
+    VINGS_CHECK_HIP(hipGetDevice(&dev));
+    VINGS_REQUIRE(dev >= 0 && dev < kMaxDev, "device index");
+    uint32_t* counts = nullptr;
+    {
+        // the address of this GPU's copy of the scratch array, looked up once per device with
+        // that device current
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        if (!g_scratch_ptr[dev])
+            VINGS_CHECK_HIP(hipGetSymbolAddress((void**)&g_scratch_ptr[dev], HIP_SYMBOL(g_compact_scratch)));
+        counts = g_scratch_ptr[dev];
+    }
+    VINGS_REQUIRE(counts != nullptr, "scratch address");
+    if (N == 0) {
+        // nothing to scan: the count word is still written, on the stream
+        VINGS_CHECK_HIP(hipMemsetAsync(n_keep_device, 0, sizeof(int64_t), s));
+        return VINGS_OK;
+    }
+    VINGS_REQUIRE(keep && dst_index, "null pointer");
+    const int nb = cdiv(N, 256);
+    // every word the later kernels read (counts[0 .. nb]) is written by the two before them:
+    // nothing of an earlier call's contents is assumed, nothing has to be cleared
+    compact_count_kernel<<<nb, 256, 0, s>>>(N, keep, counts);
+    VINGS_LAUNCH_CHECK();
+    compact_scan_kernel<<<1, 1024, 0, s>>>(counts, nb, reinterpret_cast<long long*>(n_keep_device));
+    VINGS_LAUNCH_CHECK();
+    compact_index_kernel<<<nb, 256, 0, s>>>(N, keep, counts, dst_index);
+    VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }
 
