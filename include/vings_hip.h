@@ -16,8 +16,10 @@
  *   - tensors are dense, row-major, float32 unless stated
  *   - the caller owns all device memory, including workspaces; no entry point
  *     allocates device memory.  The library itself owns two small host-side
- *     things, both created at first use and kept: a 64-byte pinned mailbox per
- *     GPU (vings_surfel_project) and the event pool of vings_profile_enable
+ *     things, both created at first use and kept: a 1 KiB ring of pinned
+ *     mailboxes per GPU (vings_surfel_project) and the event pool of
+ *     vings_profile_enable.  vings_splat_compact_plan_static uses 128 KiB of static device
+ *     memory per GPU
  *   - vings_surfel_project and vings_splat_compact_plan synchronise with the
  *     host (each returns a count the caller needs to size buffers); everything
  *     else is asynchronous on the given stream
@@ -98,10 +100,12 @@ int vings_surfel_set_tight_binning(int on);
 
 /* The same call in two halves, for callers that do not want the GPU to idle while the host
  * learns D: launch returns at once; wait blocks until the projection launched last on the
- * current GPU has finished (on an event behind it, not on the whole stream) and returns its
- * D and depth-bit range.  Between the two the caller may enqueue more work on the stream,
- * typically vings_surfel_bin_speculative and the blend sized from the previous view's count.
- * One launch may be outstanding per GPU. */
+ * current GPU BY THE CALLING THREAD has finished (on an event behind it, not on the whole
+ * stream) and returns its D and depth-bit range.  Between the two the caller may enqueue more
+ * work on the stream, typically vings_surfel_bin_speculative and the blend sized from the
+ * previous view's count.  Every launch takes its own mailbox slot and event from a ring of 16
+ * per GPU, so threads (and the streams they drive) that render on one GPU at the same time do
+ * not disturb each other; a thread's wait always refers to that thread's latest launch. */
 int vings_surfel_project_launch(int N, int H, int W, float scale_modifier,
                                 const float* means3D, const float* scales,
                                 const float* rotations, const float* opacities,
@@ -513,6 +517,22 @@ int vings_corr_index_forward(const void* volume, const float* coords, void* corr
                              int w1, int h2, int w2, int r, int half, void* stream);
 int vings_corr_index_backward(const float* coords, const void* corr_grad, void* volume_grad, int E,
                               int h1, int w1, int h2, int w2, int r, int half, void* stream);
+
+/* droid_backends.altcorr_forward / altcorr_backward (modules/corr.py:79,86-87; operands built at
+ * corr.py:106-125): the same window without the all-pairs volume.
+ *   fmap1[B,H,W,C], fmap2[B,H2,W2,C] float32 (channels last, as corr.py:102 permutes them),
+ *   coords[B,S,H,W,2] = (x, y) in fmap2 pixels, corr[B,S,(2r+1)^2,H,W].
+ * corr[b,s,i*(2r+1)+j,h,w] = bilinear sample at (x + j - r, y + i - r) of
+ * (yy, xx) -> <fmap1[b,h,w,:], fmap2[b,yy,xx,:]>, zero outside fmap2: equal to
+ * vings_corr_index_forward on volume = fmap1 . fmap2^T.  C a multiple of 4, <= 512; r <= 7.
+ * backward: fmap1_grad, fmap2_grad (same shapes as the maps, zeroed by the call) receive the
+ * adjoint of corr_grad[B,S,(2r+1)^2,H,W]; the gradient with respect to coords is not formed
+ * (the host mirror returns zeros for the third element of the reference's 3-tuple). */
+int vings_altcorr_forward(const float* fmap1, const float* fmap2, const float* coords, float* corr,
+                          int B, int S, int H, int W, int H2, int W2, int C, int r, void* stream);
+int vings_altcorr_backward(const float* fmap1, const float* fmap2, const float* coords,
+                           const float* corr_grad, float* fmap1_grad, float* fmap2_grad, int B,
+                           int S, int H, int W, int H2, int W2, int C, int r, void* stream);
 
 /* ========================================================================
  * Tracker -> mapper packaging.

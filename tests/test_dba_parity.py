@@ -279,3 +279,63 @@ def test_corr_index_forward_reference_grid(half, r):
         ref = O.corr_index_forward(tv.float().cpu().numpy(), coords, r)
         tol = 2e-3 if half else 1e-5
         np.testing.assert_allclose(got.float().cpu().numpy(), ref, rtol=tol, atol=tol)
+
+
+ALT_CASES = [
+    dict(B=6, S=1, H=43, W=77, H2=43, W2=77, C=128, r=3),        # reference grid, level 0
+    dict(B=3, S=2, H=43, W=77, H2=21, W2=38, C=128, r=3),        # a coarser pyramid level, S = 2
+    dict(B=2, S=1, H=135, W=240, H2=135, W2=240, C=128, r=3),    # 1080p / 8: no volume possible
+    dict(B=2, S=1, H=9, W=35, H2=7, W2=11, C=12, r=2),           # ragged chunk, small channels
+    dict(B=1, S=1, H=5, W=6, H2=5, W2=6, C=4, r=4),              # window larger than a wave
+]
+
+
+def _alt_inputs(c, seed=3):
+    rng = np.random.default_rng(seed)
+    f1 = rng.normal(size=(c["B"], c["H"], c["W"], c["C"])).astype(np.float32) / 4
+    f2 = rng.normal(size=(c["B"], c["H2"], c["W2"], c["C"])).astype(np.float32) / 4
+    # targets scattered over fmap2 and a margin outside it (zero padding), a few far away
+    x = rng.uniform(-5, c["W2"] + 4, size=(c["B"], c["S"], c["H"], c["W"]))
+    y = rng.uniform(-5, c["H2"] + 4, size=(c["B"], c["S"], c["H"], c["W"]))
+    x[0, 0, 0, 0] = 1e7; y[0, 0, 0, 1] = -1e7
+    return f1, f2, np.stack([x, y], -1).astype(np.float32)
+
+
+@pytest.mark.parametrize("case", ALT_CASES)
+def test_altcorr_forward_parity(case):
+    from vings_mono_amd import dba
+    dev = torch.device("cuda:0")
+    f1, f2, co = _alt_inputs(case)
+    got, = dba.altcorr_forward(torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev),
+                               torch.from_numpy(co).to(dev), case["r"])
+    want = O.altcorr_forward(f1, f2, co, case["r"])
+    assert got.shape == want.shape
+    assert rel(got.cpu().numpy(), want) < 1e-5
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=1e-5 * np.abs(want).max() + 1e-6)
+
+
+@pytest.mark.parametrize("case", ALT_CASES[:2] + ALT_CASES[3:])
+def test_altcorr_backward_parity(case):
+    from vings_mono_amd import dba
+    dev = torch.device("cuda:0")
+    f1, f2, co = _alt_inputs(case, seed=4)
+    rd2 = (2 * case["r"] + 1) ** 2
+    g = np.random.default_rng(5).normal(size=(case["B"], case["S"], rd2, case["H"], case["W"])).astype(np.float32)
+    g1, g2, gc = dba.altcorr_backward(torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev),
+                                      torch.from_numpy(co).to(dev), torch.from_numpy(g).to(dev), case["r"])
+    w1, w2 = O.altcorr_backward(f1, f2, co, g, case["r"])
+    assert rel(g1.cpu().numpy(), w1) < 1e-5 and rel(g2.cpu().numpy(), w2) < 1e-5
+    assert gc.shape == co.shape and float(gc.abs().max()) == 0.0
+
+
+def test_altcorr_equals_volume_lookup_on_the_gpu():
+    """altcorr_forward and corr_index_forward(all-pairs volume) are two routes to one window."""
+    from vings_mono_amd import dba
+    dev = torch.device("cuda:0")
+    c = dict(B=4, S=1, H=24, W=32, H2=24, W2=32, C=128, r=3)
+    f1, f2, co = _alt_inputs(c, seed=8)
+    t1, t2, tc = (torch.from_numpy(a).to(dev) for a in (f1, f2, co))
+    alt, = dba.altcorr_forward(t1, t2, tc, 3)
+    vol = torch.einsum("bhwc,byxc->bhwyx", t1, t2).contiguous()
+    ref, = dba.corr_index_forward(vol, tc[:, 0].permute(0, 3, 1, 2).contiguous(), 3)
+    assert rel(alt[:, 0].cpu().numpy(), ref.reshape(4, 49, 24, 32).cpu().numpy().astype(np.float64)) < 1e-5

@@ -191,7 +191,8 @@ def test_dropin_modules_expose_reference_names():
         sys.path.pop(0)
     for n in ("GaussianRasterizationSettings", "GaussianRasterizer", "SparseGaussianAdam"):
         assert hasattr(r, n)
-    for n in ("ba", "BACore", "frame_distance", "corr_index_forward", "corr_index_backward"):
+    for n in ("ba", "BACore", "frame_distance", "corr_index_forward", "corr_index_backward",
+              "altcorr_forward", "altcorr_backward"):
         assert hasattr(d, n)
     core = d.BACore()
     for n in ("init", "hessian", "hessian_expand", "retract"):

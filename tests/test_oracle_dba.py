@@ -247,3 +247,24 @@ def test_failed_factorisation_returns_zero_like_the_reference():
     g = np.load(GOLD)
     assert not g["bad_dx"].any()
     assert not O.solve_spd(-np.eye(12), np.ones(12)).any()
+
+
+def test_altcorr_equals_lookup_in_the_all_pairs_volume():
+    """The on-the-fly correlation window (modules/corr.py:74-125) restated position by position
+    must equal the windowed lookup (corr.py:6-20) in the all-pairs volume (corr.py:63-71) of
+    the same maps, and its backward must be the adjoint of its forward."""
+    rng = np.random.default_rng(0)
+    B, H, W, C, S, r = 2, 6, 7, 8, 2, 2
+    f1 = rng.normal(size=(B, H, W, C)); f2 = rng.normal(size=(B, 5, 9, C))
+    co = np.stack([rng.uniform(-3, 12, size=(B, S, H, W)), rng.uniform(-3, 8, size=(B, S, H, W))], -1)
+    out = O.altcorr_forward(f1, f2, co, r)
+    vol = np.einsum("bhwc,byxc->bhwyx", f1, f2)
+    for s_ in range(S):
+        ref = O.corr_index_forward(vol, np.moveaxis(co[:, s_], -1, 1), r)
+        np.testing.assert_allclose(out[:, s_], ref.reshape(B, (2 * r + 1) ** 2, H, W), atol=1e-12)
+    g = rng.normal(size=out.shape)
+    g1, g2 = O.altcorr_backward(f1, f2, co, g, r)
+    e1 = rng.normal(size=f1.shape); e2 = rng.normal(size=f2.shape); h = 1e-6
+    num = (O.altcorr_forward(f1 + h * e1, f2 + h * e2, co, r) -
+           O.altcorr_forward(f1 - h * e1, f2 - h * e2, co, r)) / (2 * h)
+    np.testing.assert_allclose((num * g).sum(), (g1 * e1).sum() + (g2 * e2).sum(), rtol=1e-7)

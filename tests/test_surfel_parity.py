@@ -418,3 +418,37 @@ def test_tight_binning_renders_the_same_bits(tight):
     assert bool((at < a.D).all())
     pos = order[at]
     assert torch.equal(ida[pos], idb) and bool(reach[pos].all()) and bool((pos[1:] > pos[:-1]).all())
+
+
+def test_two_threads_render_on_one_gpu():
+    """Two host threads, each on its own stream, render different scenes on the same GPU at
+    the same time (main map and sky model, /root/reference/scripts/gaussian/sky_utils.py:135-162):
+    every launch has its own mailbox slot, so each thread reads its own instance count and
+    gets the bits a solitary render gives."""
+    import threading
+    dev = torch.device("cuda:0")
+    jobs = [(synth.make_splats(6000, 320, 192, n_views=2, seed=61), 320, 192),
+            (synth.make_splats(15000, 256, 160, n_views=2, seed=62), 256, 160)]
+    want = [_forward_state(raw, W, H) for raw, W, H in jobs]
+    torch.cuda.synchronize()
+    errors = []
+
+    def work(k):
+        try:
+            raw, W, H = jobs[k]
+            with torch.cuda.stream(torch.cuda.Stream(dev)):
+                for _ in range(25):
+                    got = _forward_state(raw, W, H)
+                    torch.cuda.current_stream().synchronize()
+                    assert got.D == want[k].D, (k, got.D, want[k].D)
+                    assert torch.equal(got.color, want[k].color)
+                    assert torch.equal(got.ranges, want[k].ranges)
+        except Exception as exc:            # noqa: BLE001 - reported by the main thread
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

@@ -216,6 +216,167 @@ __global__ __launch_bounds__(256) void corr_index_bwd_kernel(
         }
 }
 
+// ---------------------------------------------------------------------------
+// droid_backends.altcorr_forward / altcorr_backward
+// (/root/reference/scripts/frontend/modules/corr.py:79,86-87,106-125): the correlation window
+// without the all-pairs volume.  corr[b,s,i*(2r+1)+j,h,w] is the bilinear sample at
+// (x + j - r, y + i - r), (x, y) = coords[b,s,h,w,:], of the map
+// (yy, xx) -> <fmap1[b,h,w,:], fmap2[b,yy,xx,:]>, zero outside fmap2: exactly what
+// corr_index_forward returns for volume = fmap1 . fmap2^T, but at O(H W C) memory.  At 1080p / 8
+// the volume of one edge would be 32 400^2 entries; this is the form a tracker grid of that
+// size has to use.
+// ---------------------------------------------------------------------------
+constexpr int kAltPx = 32;   // consecutive pixels of one image row per workgroup
+
+// One wave per pixel, one lane per integer position of the (2r+2)^2 neighbourhood: the lane
+// walks its fmap2 row against the pixel's fmap1 row (broadcast from LDS).  The 32 pixels of a
+// workgroup leave their windows in LDS and are stored with the pixel index fastest, so every
+// store instruction covers full lines of one output plane.
+__global__ __launch_bounds__(256) void altcorr_fwd_kernel(
+    const float* __restrict__ fmap1, const float* __restrict__ fmap2,
+    const float* __restrict__ coords, float* __restrict__ corr, int B, int S, int H, int W, int H2,
+    int W2, int C, int r) {
+    extern __shared__ float alt_lds[];
+    const int n1 = 2 * r + 2, P = n1 * n1, rd = 2 * r + 1, K = rd * rd;
+    float* f1 = alt_lds;                       // [kAltPx][C]
+    float* dots = f1 + kAltPx * C;             // [4 waves][P]
+    float* tile = dots + 4 * P;                // [K][kAltPx]
+    const int chunks = (W + kAltPx - 1) / kAltPx;
+    int blk = blockIdx.x;
+    const int wc = blk % chunks; blk /= chunks;
+    const int h = blk % H; blk /= H;
+    const int s = blk % S;
+    const int b = blk / S;
+    const int w0 = wc * kAltPx, npx = min(kAltPx, W - w0);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // fmap1 rows of the chunk: contiguous in memory
+    {
+        const float* src = fmap1 + (((size_t)b * H + h) * W + w0) * C;
+        for (int k = threadIdx.x; k < npx * C; k += 256) f1[k] = src[k];
+    }
+    __syncthreads();
+    const int C4 = C >> 2;
+    for (int p = wv; p < npx; p += 4) {
+        const float* cp = coords + ((((size_t)b * S + s) * H + h) * W + (w0 + p)) * 2;
+        const float x = cp[0], y = cp[1];
+        // coordinates far outside (or not finite) see nothing; the bound keeps the casts defined
+        const bool sane = fabsf(x) < 1e6f && fabsf(y) < 1e6f;
+        const float xf = sane ? floorf(x) : -1e6f, yf = sane ? floorf(y) : -1e6f;
+        const float dx = sane ? x - xf : 0.f, dy = sane ? y - yf : 0.f;
+        const int x0 = (int)xf - r, y0 = (int)yf - r;
+        const float4* a4 = reinterpret_cast<const float4*>(f1 + p * C);
+        for (int q = lane; q < P; q += 64) {
+            const int iy = q / n1, ix = q - iy * n1;
+            const int yy = y0 + iy, xx = x0 + ix;
+            float acc = 0.f;
+            if (yy >= 0 && yy < H2 && xx >= 0 && xx < W2) {
+                const float4* row = reinterpret_cast<const float4*>(
+                    fmap2 + (((size_t)b * H2 + yy) * W2 + xx) * C);
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
+                for (int c = 0; c < C4; ++c) {
+                    const float4 u = row[c], v = a4[c];
+                    a0 += u.x * v.x; a1 += u.y * v.y; a2 += u.z * v.z; a3 += u.w * v.w;
+                }
+                acc = (a0 + a1) + (a2 + a3);
+            }
+            dots[wv * P + q] = acc;
+        }
+        // same wave wrote and reads: LDS operations of a wave complete in order
+        __builtin_amdgcn_wave_barrier();
+        const float w00 = (1.f - dx) * (1.f - dy), w01 = dx * (1.f - dy), w10 = (1.f - dx) * dy,
+                    w11 = dx * dy;
+        const float* d = dots + wv * P;
+        for (int k = lane; k < K; k += 64) {
+            const int i = k / rd, j = k - i * rd;
+            const float* e = d + i * n1 + j;
+            tile[k * kAltPx + p] = w00 * e[0] + w01 * e[1] + w10 * e[n1] + w11 * e[n1 + 1];
+        }
+    }
+    __syncthreads();
+    float* out = corr + ((((size_t)b * S + s) * K) * H + h) * W + w0;
+    for (int k = threadIdx.x; k < K * kAltPx; k += 256) {
+        const int kk = k / kAltPx, p = k - kk * kAltPx;
+        if (p < npx) out[(size_t)kk * H * W + p] = tile[k];
+    }
+}
+
+// Adjoint with respect to both feature maps.  One wave per (b, s, h, w); the lanes first fold
+// corr_grad back onto the (2r+2)^2 integer positions (adjoint of the bilinear weights), then
+// own channels: for every position with a non-zero weight the pixel's fmap1 row is added into
+// that fmap2_grad row (coalesced float atomics, C contiguous floats) and the fmap2 row is
+// accumulated into the pixel's fmap1_grad row, which is added once at the end (pixels of
+// different s share it).
+__global__ __launch_bounds__(256) void altcorr_bwd_kernel(
+    const float* __restrict__ fmap1, const float* __restrict__ fmap2,
+    const float* __restrict__ coords, const float* __restrict__ corr_grad,
+    float* __restrict__ fmap1_grad, float* __restrict__ fmap2_grad, int B, int S, int H, int W,
+    int H2, int W2, int C, int r, long long n_pix) {
+    extern __shared__ float alt_lds[];
+    const int n1 = 2 * r + 2, P = n1 * n1, rd = 2 * r + 1, K = rd * rd;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* gpos = alt_lds + wv * P;
+    const long long pix = (long long)blockIdx.x * 4 + wv;
+    if (pix >= n_pix) return;
+    long long t = pix;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H); t /= H;
+    const int s = (int)(t % S);
+    const int b = (int)(t / S);
+    const float* cp = coords + (size_t)pix * 2;
+    const float x = cp[0], y = cp[1];
+    const bool sane = fabsf(x) < 1e6f && fabsf(y) < 1e6f;
+    const float xf = sane ? floorf(x) : -1e6f, yf = sane ? floorf(y) : -1e6f;
+    const float dx = sane ? x - xf : 0.f, dy = sane ? y - yf : 0.f;
+    const int x0 = (int)xf - r, y0 = (int)yf - r;
+    const float w00 = (1.f - dx) * (1.f - dy), w01 = dx * (1.f - dy), w10 = (1.f - dx) * dy,
+                w11 = dx * dy;
+    const float* g = corr_grad + ((((size_t)b * S + s) * K) * H + h) * W + w;
+    const size_t plane = (size_t)H * W;
+    for (int q = lane; q < P; q += 64) {
+        const int iy = q / n1, ix = q - iy * n1;
+        float v = 0.f;
+        if (iy < rd && ix < rd) v += w00 * g[(size_t)(iy * rd + ix) * plane];
+        if (iy < rd && ix > 0) v += w01 * g[(size_t)(iy * rd + ix - 1) * plane];
+        if (iy > 0 && ix < rd) v += w10 * g[(size_t)((iy - 1) * rd + ix) * plane];
+        if (iy > 0 && ix > 0) v += w11 * g[(size_t)((iy - 1) * rd + ix - 1) * plane];
+        gpos[q] = v;
+    }
+    __builtin_amdgcn_wave_barrier();     // the wave's own LDS writes, read back below in order
+    const float* a = fmap1 + (((size_t)b * H + h) * W + w) * C;
+    constexpr int kMaxPerLane = 8;                      // C <= 512
+    float f1v[kMaxPerLane], acc[kMaxPerLane];
+#pragma unroll
+    for (int k = 0; k < kMaxPerLane; ++k) {
+        const int c = lane + 64 * k;
+        f1v[k] = c < C ? a[c] : 0.f;
+        acc[k] = 0.f;
+    }
+    for (int q = 0; q < P; ++q) {
+        const float gq = gpos[q];                       // broadcast; written by this wave
+        if (gq == 0.f) continue;                        // wave-uniform
+        const int iy = q / n1, ix = q - iy * n1;
+        const int yy = y0 + iy, xx = x0 + ix;
+        if (yy < 0 || yy >= H2 || xx < 0 || xx >= W2) continue;
+        const size_t off = (((size_t)b * H2 + yy) * W2 + xx) * C;
+#pragma unroll
+        for (int k = 0; k < kMaxPerLane; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C) {
+                acc[k] += gq * fmap2[off + c];
+                atomicAdd(fmap2_grad + off + c, gq * f1v[k]);
+            }
+        }
+    }
+    float* o = fmap1_grad + (((size_t)b * H + h) * W + w) * C;
+#pragma unroll
+    for (int k = 0; k < kMaxPerLane; ++k) {
+        const int c = lane + 64 * k;
+        if (c < C && acc[k] != 0.f) atomicAdd(o + c, acc[k]);
+    }
+}
+
+
 }  // namespace vings
 
 using namespace vings;
@@ -280,6 +441,58 @@ extern "C" int vings_corr_index_backward(const float* coords, const void* corr_g
     else
         corr_index_bwd_kernel<float><<<cdiv(n, 256), 256, 0, s>>>(
             coords, (const float*)corr_grad, (float*)volume_grad, E, h1, w1, h2, w2, r);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}
+
+static int altcorr_check(int B, int S, int H, int W, int H2, int W2, int C, int r) {
+    VINGS_REQUIRE(B >= 0 && S > 0 && H > 0 && W > 0 && H2 > 0 && W2 > 0, "sizes");
+    VINGS_REQUIRE(C > 0 && (C & 3) == 0 && C <= 512, "channels: a multiple of 4, at most 512");
+    VINGS_REQUIRE(r >= 0 && r <= 7, "radius 0..7");
+    return VINGS_OK;
+}
+
+extern "C" int vings_altcorr_forward(const float* fmap1, const float* fmap2, const float* coords,
+                                     float* corr, int B, int S, int H, int W, int H2, int W2, int C,
+                                     int r, void* stream) {
+    const int rc = altcorr_check(B, S, H, W, H2, W2, C, r);
+    if (rc != VINGS_OK) return rc;
+    if (B == 0) return VINGS_OK;
+    VINGS_REQUIRE(fmap1 && fmap2 && coords && corr, "null pointer");
+    VINGS_REQUIRE((((uintptr_t)fmap1 | (uintptr_t)fmap2) & 15) == 0, "feature maps must be 16-byte aligned");
+    const int n1 = 2 * r + 2, rd = 2 * r + 1;
+    const size_t lds = sizeof(float) * ((size_t)kAltPx * C + 4 * n1 * n1 + (size_t)rd * rd * kAltPx);
+    VINGS_REQUIRE(lds <= 160 * 1024, "window and channel count exceed the LDS of a CU");
+    const long long blocks = (long long)B * S * H * cdiv(W, kAltPx);
+    VINGS_REQUIRE(blocks < (1ll << 31), "grid too large");
+    if (lds > 64 * 1024)
+        VINGS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(altcorr_fwd_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope prof(PROF_AUX, (hipStream_t)stream);
+    altcorr_fwd_kernel<<<(int)blocks, 256, lds, (hipStream_t)stream>>>(fmap1, fmap2, coords, corr, B, S,
+                                                                      H, W, H2, W2, C, r);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}
+
+extern "C" int vings_altcorr_backward(const float* fmap1, const float* fmap2, const float* coords,
+                                      const float* corr_grad, float* fmap1_grad, float* fmap2_grad,
+                                      int B, int S, int H, int W, int H2, int W2, int C, int r,
+                                      void* stream) {
+    const int rc = altcorr_check(B, S, H, W, H2, W2, C, r);
+    if (rc != VINGS_OK) return rc;
+    if (B == 0) return VINGS_OK;
+    VINGS_REQUIRE(fmap1 && fmap2 && coords && corr_grad && fmap1_grad && fmap2_grad, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    VINGS_CHECK_HIP(hipMemsetAsync(fmap1_grad, 0, sizeof(float) * (size_t)B * H * W * C, s));
+    VINGS_CHECK_HIP(hipMemsetAsync(fmap2_grad, 0, sizeof(float) * (size_t)B * H2 * W2 * C, s));
+    const long long n_pix = (long long)B * S * H * W;
+    const long long blocks = (n_pix + 3) / 4;
+    VINGS_REQUIRE(blocks < (1ll << 31), "grid too large");
+    const int n1 = 2 * r + 2;
+    ProfScope prof(PROF_AUX, s);
+    altcorr_bwd_kernel<<<(int)blocks, 256, sizeof(float) * 4 * n1 * n1, s>>>(
+        fmap1, fmap2, coords, corr_grad, fmap1_grad, fmap2_grad, B, S, H, W, H2, W2, C, r, n_pix);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }

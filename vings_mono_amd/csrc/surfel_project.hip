@@ -498,14 +498,23 @@ __global__ __launch_bounds__(256) void project_bwd_finish_kernel(
                  make_float4(g.dq[0], g.dq[1], g.dq[2], g.dq[3]), g.sc[0], g.sc[1]);
 }
 
-// One 64-byte pinned, device-visible host buffer per GPU, created at the first projection call
-// on that GPU and kept for the life of the process (the only memory this library owns besides
-// the optional event pool).  A pageable device-to-host copy costs ~50 us more per view.
+// The instance count of a view comes back through pinned, device-visible host memory: a pageable
+// device-to-host copy costs ~50 us more per view.  Every GPU gets a ring of kMailSlots 64-byte
+// mailboxes with an event each, created at the first projection call on that GPU and kept for
+// the life of the process (the only memory this library owns besides the optional event pool).
+// Every launch takes the next slot of its GPU's ring and remembers it in the calling thread;
+// vings_surfel_project_wait reads the slot of the calling thread's latest launch.  So host
+// threads (or streams driven from different threads) that render on one GPU at the same time
+// do not see each other's counts; one thread may have kMailSlots launches in flight before a
+// slot is reused, although its wait() only ever returns the latest one.
 namespace {
 constexpr int kMaxDevices = 64;
+constexpr int kMailSlots = 16;
 std::mutex g_mail_mu[kMaxDevices];
-uint32_t* g_mail[kMaxDevices] = {};
-hipEvent_t g_mail_evt[kMaxDevices] = {};
+uint32_t* g_mail[kMaxDevices] = {};                      // kMailSlots * 16 words
+hipEvent_t g_mail_evt[kMaxDevices][kMailSlots] = {};
+std::atomic<unsigned> g_mail_next[kMaxDevices];
+thread_local int t_mail_dev = -1, t_mail_slot = -1;      // the calling thread's latest launch
 // 1: a splat is binned only into the tiles its alpha >= 1/255 box reaches (the default);
 // 0: into every tile of the reference's 3-sigma square (forward.cu preprocess / getRect).
 std::atomic<int> g_tight_binning{1};
@@ -534,8 +543,17 @@ static int project_launch(int N, int H, int W, float scale_modifier, const float
     int dev = 0;
     VINGS_CHECK_HIP(hipGetDevice(&dev));
     VINGS_REQUIRE(dev >= 0 && dev < kMaxDevices, "device index");
-    if (!g_mail[dev]) VINGS_CHECK_HIP(hipHostMalloc((void**)&g_mail[dev], 64, hipHostMallocDefault));
-    if (!g_mail_evt[dev]) VINGS_CHECK_HIP(hipEventCreateWithFlags(&g_mail_evt[dev], hipEventDisableTiming));
+    {
+        std::lock_guard<std::mutex> lk(g_mail_mu[dev]);
+        if (!g_mail[dev]) {
+            uint32_t* m = nullptr;
+            VINGS_CHECK_HIP(hipHostMalloc((void**)&m, 64 * kMailSlots, hipHostMallocDefault));
+            for (int k = 0; k < kMailSlots; ++k)
+                VINGS_CHECK_HIP(hipEventCreateWithFlags(&g_mail_evt[dev][k], hipEventDisableTiming));
+            g_mail[dev] = m;
+        }
+    }
+    const int slot = (int)(g_mail_next[dev].fetch_add(1u, std::memory_order_relaxed) % kMailSlots);
     const int nb = cdiv(N, 256);
     const int tight = g_tight_binning.load(std::memory_order_relaxed);
     {
@@ -552,16 +570,21 @@ static int project_launch(int N, int H, int W, float scale_modifier, const float
             block_prefix, block_prefix + nb + 1, block_prefix + 2 * nb + 1, tight, nullptr);
     VINGS_LAUNCH_CHECK();
     }
-    scan_blocks_kernel<<<1, 1024, 0, s>>>(block_prefix, nb, g_mail[dev]);
+    scan_blocks_kernel<<<1, 1024, 0, s>>>(block_prefix, nb, g_mail[dev] + 16 * slot);
     VINGS_LAUNCH_CHECK();
-    VINGS_CHECK_HIP(hipEventRecord(g_mail_evt[dev], s));
+    VINGS_CHECK_HIP(hipEventRecord(g_mail_evt[dev][slot], s));
+    t_mail_dev = dev;
+    t_mail_slot = slot;
     *dev_out = dev;
     return VINGS_OK;
 }
 
 static int project_wait(int dev, int64_t* num_instances_host, uint32_t* depth_bits_range_host) {
-    VINGS_CHECK_HIP(hipEventSynchronize(g_mail_evt[dev]));
-    volatile uint32_t* tail = g_mail[dev];   // depth-bit min, max, instance total
+    VINGS_REQUIRE(t_mail_dev == dev && t_mail_slot >= 0,
+                  "this thread has launched no projection on the current GPU");
+    const int slot = t_mail_slot;
+    VINGS_CHECK_HIP(hipEventSynchronize(g_mail_evt[dev][slot]));
+    volatile uint32_t* tail = g_mail[dev] + 16 * slot;   // depth-bit min, max, instance total
     *num_instances_host = (int64_t)tail[2];
     if (depth_bits_range_host) {
         depth_bits_range_host[0] = tail[2] > 0 ? tail[0] : 0u;
@@ -587,8 +610,6 @@ extern "C" int vings_surfel_project(int N, int H, int W, float scale_modifier,
     int cur = 0;
     VINGS_CHECK_HIP(hipGetDevice(&cur));
     VINGS_REQUIRE(cur >= 0 && cur < kMaxDevices, "device index");
-    // held until the words are read: calls on one GPU share its mailbox
-    std::lock_guard<std::mutex> lk(g_mail_mu[cur]);
     int dev = 0;
     const int rc = project_launch(N, H, W, scale_modifier, means3D, scales, rotations, opacities,
                                   colors, flow, viewmatrix, projmatrix, geom, depth, radii, rect,
@@ -638,7 +659,7 @@ extern "C" int vings_surfel_project_wait(int64_t* num_instances_host,
     VINGS_REQUIRE(num_instances_host != nullptr, "num_instances_host");
     int dev = 0;
     VINGS_CHECK_HIP(hipGetDevice(&dev));
-    VINGS_REQUIRE(dev >= 0 && dev < kMaxDevices && g_mail_evt[dev], "no projection was launched on this GPU");
+    VINGS_REQUIRE(dev >= 0 && dev < kMaxDevices && g_mail[dev], "no projection was launched on this GPU");
     return project_wait(dev, num_instances_host, depth_bits_range_host);
 }
 

@@ -1,9 +1,10 @@
 """Host-side mirror of the reference's ``droid_backends`` extension: ``ba``,
-``BACore``, ``frame_distance``, ``corr_index_forward`` / ``corr_index_backward``.
+``BACore``, ``frame_distance``, ``corr_index_forward`` / ``corr_index_backward``,
+``altcorr_forward`` / ``altcorr_backward``.
 
 Same call signatures as used at
 /root/reference/scripts/frontend/depth_video.py:289-299,380-381,475-481,554-568,618,650
-and /root/reference/scripts/frontend/modules/corr.py:12,19.  Compute happens in
+and /root/reference/scripts/frontend/modules/corr.py:12,19,79,86-87.  Compute happens in
 libvings_hip.so through the C ABI (include/vings_hip.h); torch provides device
 memory and the current stream.
 """
@@ -42,6 +43,8 @@ def _fn(name):
             "vings_frame_distance": (_I, [_P] * 5 + [_I] * 4 + [_c.c_float, _P, _P]),
             "vings_corr_index_forward": (_I, [_P] * 3 + [_I] * 7 + [_P]),
             "vings_corr_index_backward": (_I, [_P] * 3 + [_I] * 7 + [_P]),
+            "vings_altcorr_forward": (_I, [_P] * 4 + [_I] * 8 + [_P]),
+            "vings_altcorr_backward": (_I, [_P] * 6 + [_I] * 8 + [_P]),
         }
         res, args = sigs[name]
         _bound[name] = _lib.bind(name, res, args)
@@ -255,6 +258,46 @@ def corr_index_backward(volume, coords, corr_grad, radius):
     check(_fn("vings_corr_index_backward")(ptr(coords), ptr(corr_grad), ptr(grad), *dims,
                                            stream_ptr(volume.device)), "vings_corr_index_backward")
     return [grad]
+
+
+def _altcorr_args(fmap1, fmap2, coords, radius):
+    fmap1 = _gpu_f32(fmap1, "fmap1")
+    fmap2 = _gpu_f32(fmap2, "fmap2")
+    coords = _gpu_f32(coords, "coords")
+    if fmap1.dim() != 4 or fmap2.dim() != 4 or coords.dim() != 5:
+        raise _lib.VingsError("expected fmap1[B,H,W,C], fmap2[B,H2,W2,C], coords[B,S,H,W,2]")
+    B, H, W, C = fmap1.shape
+    B2, H2, W2, C2 = fmap2.shape
+    if B2 != B or C2 != C or tuple(coords.shape[0:1] + coords.shape[2:]) != (B, H, W, 2):
+        raise _lib.VingsError("fmap1 / fmap2 / coords shapes do not belong together")
+    return fmap1, fmap2, coords, (B, int(coords.shape[1]), H, W, H2, W2, C, int(radius))
+
+
+def altcorr_forward(fmap1, fmap2, coords, radius):
+    """Correlation window computed on the fly (modules/corr.py:79): fmap1[B,H,W,C],
+    fmap2[B,H2,W2,C], coords[B,S,H,W,2] -> 1-tuple (corr[B,S,(2r+1)^2,H,W],)."""
+    fmap1, fmap2, coords, dims = _altcorr_args(fmap1, fmap2, coords, radius)
+    B, S, H, W, _, _, _, r = dims
+    corr = torch.empty((B, S, (2 * r + 1) ** 2, H, W), dtype=torch.float32, device=fmap1.device)
+    check(_fn("vings_altcorr_forward")(ptr(fmap1), ptr(fmap2), ptr(coords), ptr(corr), *dims,
+                                       stream_ptr(fmap1.device)), "vings_altcorr_forward")
+    return [corr]
+
+
+def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
+    """3-tuple (fmap1_grad, fmap2_grad, coords_grad) as unpacked at modules/corr.py:86-87;
+    coords_grad is zero (the lookup is not differentiated with respect to its position, and the
+    tracker runs under no_grad, dbaf.py:61)."""
+    fmap1, fmap2, coords, dims = _altcorr_args(fmap1, fmap2, coords, radius)
+    B, S, H, W, _, _, _, r = dims
+    corr_grad = _gpu_f32(corr_grad, "corr_grad")
+    if tuple(corr_grad.shape) != (B, S, (2 * r + 1) ** 2, H, W):
+        raise _lib.VingsError("corr_grad must be [B,S,(2r+1)^2,H,W]")
+    g1, g2 = torch.empty_like(fmap1), torch.empty_like(fmap2)
+    check(_fn("vings_altcorr_backward")(ptr(fmap1), ptr(fmap2), ptr(coords), ptr(corr_grad), ptr(g1),
+                                        ptr(g2), *dims, stream_ptr(fmap1.device)),
+          "vings_altcorr_backward")
+    return [g1, g2, torch.zeros_like(coords)]
 
 
 # ---------------------------------------------------------------------------

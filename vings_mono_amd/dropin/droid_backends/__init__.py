@@ -11,7 +11,8 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 
-from vings_mono_amd.dba import (BACore, ba, corr_index_backward, corr_index_forward,  # noqa: E402,F401
-                                frame_distance)
+from vings_mono_amd.dba import (BACore, altcorr_backward, altcorr_forward, ba,  # noqa: E402,F401
+                                corr_index_backward, corr_index_forward, frame_distance)
 
-__all__ = ["ba", "BACore", "frame_distance", "corr_index_forward", "corr_index_backward"]
+__all__ = ["ba", "BACore", "frame_distance", "corr_index_forward", "corr_index_backward",
+           "altcorr_forward", "altcorr_backward"]
