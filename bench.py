@@ -32,11 +32,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=("auto", "c3", "c4"), default="auto",
+    ap.add_argument("--workload", choices=("auto", "c3", "c4", "c5"), default="auto",
                     help="BASELINE config: c3 = 8-keyframe window + DBA on every GPU (the one the "
                          "metric is quoted on); c4 = one 32-keyframe window whose keyframes are "
-                         "dealt out over the GPUs (4 per GPU at 8); auto = c4 at 8 GPUs, else c3")
-    ap.add_argument("--splats", type=int, default=1_000_000)
+                         "dealt out over the GPUs (4 per GPU at 8); c5 = 5.0M splats, 8 keyframes "
+                         "dealt out over the GPUs + DBA + the GPU side of one loop closure over 64 "
+                         "history keyframes per step; auto = c4 at 8 GPUs, else c3")
+    ap.add_argument("--splats", type=int, default=None, help="default 1.0M (c5: 5.0M)")
+    ap.add_argument("--loop-keyframes", type=int, default=64, help="c5: history keyframes K")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--views", type=int, default=None,
@@ -113,9 +116,28 @@ def main():
     if workload == "auto":
         workload = "c4" if world == 8 else "c3"
     W, H = args.width, args.height
+    if args.splats is None:
+        args.splats = 5_000_000 if workload == "c5" else 1_000_000
     intr = synth.intrinsic_for(W, H)
     surfel.set_tight_binning(args.binning == "tight")
-    if workload == "c3":
+    loop = None
+    if workload == "c5":
+        # BASELINE config 5: a 5.0M-splat map along a street of K history keyframes; the 8 most
+        # recent keyframes are the mapping window, dealt out over the GPUs (1 per GPU at 8).
+        # Every step also runs the GPU side of one loop closure over all K keyframes
+        # (loop_model.py:169-214, loop_rectify.py:300-437).  That part is not sharded: every
+        # rank does it on its own replica ("replicas only"), with an identity correction so
+        # that the map of the next step is the same.  The pose-graph solve itself (scipy /
+        # GTSAM on the host) is not part of this path.
+        K = args.loop_keyframes
+        window = 8
+        V = args.views or max(1, window // world)
+        raw = synth.make_splats(args.splats, W, H, n_views=K, seed=5, z_range=(2.0, 120.0))
+        c2w_all = synth.window_poses(K)
+        c2w_rank = c2w_all[K - window + (rank * V) % window:][:V]
+        assert c2w_rank.shape[0] == V, "views per GPU x GPUs must fit the 8-keyframe window"
+        loop = {"K": K, "c2w": [p.clone() for p in c2w_all]}
+    elif workload == "c3":
         # Identical splat replica on every rank, filling the frustum union of ONE V-keyframe
         # window.  Every rank films that window from its own height (5 cm apart), so all ranks
         # see the same share of the map: the work per GPU stays what it is at N = 1 (weak
@@ -148,6 +170,28 @@ def main():
                         "depth_cov": torch.ones_like(depth)})
     del gt_mapper_params
     reducer = parallel.GradReducer(mapper.n, dev, world)
+    if loop is not None:
+        from vings_mono_amd import maintenance
+        loop["c2w"] = [p.to(dev) for p in loop["c2w"]]
+        loop["stack"] = torch.stack(loop["c2w"])
+        loop["dense"] = torch.zeros((loop["K"], H, W), device=dev)
+        loop["coarse"] = torch.zeros((loop["K"], H // 8, W // 8), device=dev)
+        loop["ms"] = {}
+
+    def loop_closure():
+        """GPU side of one loop closure: top-3 keyframe scoring of every splat, re-anchoring
+        (identity correction: the kernels run, the map stays), tracker depth refresh."""
+        K = loop["K"]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+        scores3, ids3 = maintenance.calc_score(mapper, loop["c2w"], list(range(K)), intr)
+        ev[1].record()
+        maintenance.rectify_gaussians(mapper, loop["stack"], loop["stack"], torch.ones(K), 0, K - 1,
+                                      scores3, ids3, delete_below=-1.0)
+        ev[2].record()
+        maintenance.rectify_tracker(mapper, loop["c2w"], intr, loop["dense"], loop["coarse"])
+        ev[3].record()
+        loop["events"] = ev
 
     dba = None
     if not args.no_dba:
@@ -178,6 +222,8 @@ def main():
             dba.run()
         if finish_records is not None:
             finish_records()
+        if loop is not None:
+            loop_closure()
 
     def barrier():
         if world > 1:
@@ -225,7 +271,7 @@ def main():
         return round(n_views_total * n_steps / (time.perf_counter() - t), 3)
 
     reference_api = reference_binning = None
-    if world == 1 and not args.no_side_runs and not (args.autograd or args.torch_loss):
+    if world == 1 and not args.no_side_runs and not (args.autograd or args.torch_loss) and loop is None:
         # the reference's own call pattern (gaussian_base.py:367-403): PyTorch activations,
         # GaussianRasterizer through autograd, the PyTorch loss graph, loss.backward(), PyTorch
         # score bookkeeping, SparseGaussianAdam.step -- through the drop-in names
@@ -252,11 +298,16 @@ def main():
                         "(profiles/, null for any other workload).  The kernel is bound by "
                         "vector-instruction issue, not by HBM (profiles/*/blend_sq_counters.txt)"}
     stage_ms = {k: round(v["ms"] / max(v["count"], 1), 4) for k, v in prof_all.items()}
+    if loop is not None:
+        ev = loop["events"]
+        stage_ms.update({"loop_score_top3": round(ev[0].elapsed_time(ev[1]), 3),
+                         "loop_reanchor": round(ev[1].elapsed_time(ev[2]), 3),
+                         "loop_tracker_refresh": round(ev[2].elapsed_time(ev[3]), 3)})
     if roof is not None:
         stage_ms["blend_bwd"] = roof["avg_kernel_ms"]     # the timed region's own figure
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and workload == "c3":
         from oracle import cpu_baseline
         cpu = cpu_baseline.run(args.splats, W, H, V, dba_problem=None if dba is None else dba.np,
                                dba_itrs=2 if dba is None else dba.itrs, window=V)
@@ -272,7 +323,10 @@ def main():
                                         workload[1], args.splats / 1e6,
                                         ("%d-keyframe window per GPU" % V) if workload == "c3" else
                                         ("one %d-keyframe window, %d keyframes per GPU" % (window, V)),
-                                        W, H, "" if dba is None else " + DBA step per GPU")),
+                                        W, H, ("" if dba is None else " + DBA step per GPU") +
+                                        ("" if loop is None else " + loop closure over %d keyframes "
+                                         "per step (scoring, re-anchor, tracker refresh; replicated "
+                                         "on every GPU; pose-graph solve excluded)" % loop["K"]))),
                        "binning": args.binning,
                        "view_step": "autograd" if (args.autograd or args.torch_loss) else "fused C-ABI sequence",
                        "loss": "torch graph" if args.torch_loss else "fused HIP kernels",

@@ -206,3 +206,76 @@ def test_speculative_launch_equals_exact_launch_at_benchmark_size(full_scene):
             assert torch.equal(getattr(want, name), getattr(got, name)), name
         assert torch.equal(want.keys[:want.D], got.keys[:got.D])
         assert torch.equal(want.vals[:want.D], got.vals[:got.D])
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE config 5: 5.0 M splats along a street of 64 keyframes (the loop-closure size)
+# ---------------------------------------------------------------------------------------------
+N5, K5 = 5_000_000, 64
+
+
+@pytest.fixture(scope="module")
+def street_scene():
+    dev = torch.device("cuda:0")
+    raw = synth.make_splats(N5, W, H, n_views=K5, seed=5, z_range=(2.0, 120.0))
+    act = {k: v.to(dev).contiguous() for k, v in synth.activate(raw).items()}
+    c2w = synth.window_poses(K5)[60]
+    cam = synth.Camera(torch.linalg.inv(c2w).to(dev), synth.intrinsic_for(W, H))
+    settings = surfel.GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+        bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+        projmatrix=cam.full_proj_transform, sh_degree=0, campos=cam.camera_center,
+        prefiltered=False, debug=False)
+    st, aux = surfel.rasterize_forward(act["means3D"], act["colors"], act["opacities"],
+                                       act["scales"], act["rotations"], settings, keep_keys=True)
+    torch.cuda.synchronize()
+    return raw, act, settings, st, aux
+
+
+def test_street_instance_list_is_sorted_and_partitioned(street_scene):
+    raw, act, settings, st, aux = street_scene
+    D = st.D
+    assert D > 2 * N5 // 5
+    keys = st.keys[:D]
+    assert bool((keys[1:] >= keys[:-1]).all())
+    tile = (keys >> 32).to(torch.int64)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    counts = torch.bincount(tile, minlength=T)
+    r = st.ranges.to(torch.int64)
+    assert torch.equal(r[:, 1] - r[:, 0], counts)
+    per_splat = torch.bincount(st.vals[:D].to(torch.int64), minlength=N5)
+    want = torch.where(st.radii > 0, st.tiles_touched[:N5], torch.zeros_like(st.tiles_touched[:N5]))
+    assert torch.equal(per_splat, want.to(torch.int64))
+
+
+def test_street_importance_pass_conserves_blend_weight(street_scene):
+    """The forward-only importance pass of loop-closure scoring (loop_model.py:169-214):
+    sum over splats of the weight mass = sum over pixels of alpha, and it equals the score the
+    backward pass leaves under a zero upstream gradient."""
+    raw, act, settings, st, aux = street_scene
+    dev = st.color.device
+    imp, radii = surfel.view_importance(act["means3D"], act["colors"], act["opacities"],
+                                        act["scales"], act["rotations"], settings)
+    total_alpha = float(st.allmap[1].double().sum())
+    assert abs(float(imp.double().sum()) - total_alpha) <= 1e-4 * total_alpha
+    assert torch.equal(radii, st.radii)
+    out = surfel.rasterize_backward(st, aux, act["means3D"], act["scales"], act["rotations"], 1.0,
+                                    torch.zeros(3, H, W, device=dev), torch.zeros(9, H, W, device=dev))
+    s0 = out[6][:, 0]
+    assert float((s0 - imp).abs().max()) <= 1e-4 * float(imp.max())
+
+
+def test_street_compaction_is_bit_exact(street_scene):
+    """Pruning at the 5 M size: one plan + one copy launch over parameters, moments and records
+    equals boolean indexing array by array (gaussian_base.py:94-110), bit for bit."""
+    from vings_mono_amd import maintenance
+    raw, act, settings, st, aux = street_scene
+    dev = st.color.device
+    keep = torch.rand(N5, generator=torch.Generator().manual_seed(3)).to(dev) > 0.23
+    arrays = [act["means3D"], act["colors"], act["opacities"], act["scales"], act["rotations"],
+              st.radii, (torch.arange(N5, device=dev) % 251).to(torch.uint8),
+              torch.arange(N5, device=dev, dtype=torch.int64)]
+    outs, m = maintenance.compact(arrays, keep)
+    assert m == int(keep.sum())
+    for a, o in zip(arrays, outs):
+        assert torch.equal(o, a[keep])
