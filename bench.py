@@ -55,6 +55,10 @@ def parse():
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="all ranks share GPU 0 and exchange over gloo: checks the multi-rank "
                          "path on a one-GPU box; the figure printed is not a benchmark result")
+    ap.add_argument("--exchange", choices=("compact", "planar"), default="compact",
+                    help="N > 1: compact = only the rows some rank touched travel, in chunks "
+                         "applied while the next one is reduced; planar = all rows in one all-reduce")
+    ap.add_argument("--exchange-chunks", type=int, default=4)
     ap.add_argument("--autograd", action="store_true",
                     help="drive the view step through torch autograd and PyTorch bookkeeping "
                          "instead of the fused C-ABI sequence")
@@ -169,7 +173,8 @@ def main():
             gts.append({"rgb": pred["rgb"].clone(), "depth": depth,
                         "depth_cov": torch.ones_like(depth)})
     del gt_mapper_params
-    reducer = parallel.GradReducer(mapper.n, dev, world)
+    reducer = parallel.GradReducer(mapper.n, dev, world, n_chunks=args.exchange_chunks,
+                                   compact=args.exchange == "compact")
     if loop is not None:
         from vings_mono_amd import maintenance
         loop["c2w"] = [p.to(dev) for p in loop["c2w"]]
@@ -333,7 +338,11 @@ def main():
                        "splats": args.splats, "width": W, "height": H, "views_per_gpu": V,
                        "dba": None if dba is None else dba.describe(),
                        "instances_D": stats["D"], "visible": stats["n_vis"],
-                       "parallelism": f"views sharded over {world} GPU(s), grad all-reduce"},
+                       "parallelism": f"views sharded over {world} GPU(s), grad all-reduce",
+                       "exchange": None if world == 1 else (
+                           {"form": "planar", "rows": mapper.n} if reducer.last_exchanged_rows is None
+                           else {"form": "compact", "chunks": args.exchange_chunks,
+                                 "rows": reducer.last_exchanged_rows, "of": mapper.n})},
             "roofline": roof, "cpu_baseline": cpu, "stage_ms": stage_ms,
             "reference_api": None if reference_api is None else {
                 "value": reference_api, "unit": "frames/s",

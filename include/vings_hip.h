@@ -282,6 +282,48 @@ int vings_surfel_project_backward_finish(
     int64_t* record_keys, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Compact exchange of one view step between the GPUs of a sharded mapping job (one process
+ * per GPU, every GPU holds the whole splat set and renders its own keyframe; the reference is
+ * single-GPU, configs/hierarchical/smallcity.yaml:11-13, so these have no counterpart there).
+ * Only the rows some rank touched travel, in chunks that are reduced and applied one after
+ * the other:
+ *   1. vings_splat_touched          touched[i] = radii[i] > 0  (then MAX over the ranks)
+ *   2. vings_splat_compact_plan_device  slot_of_row from the reduced mask; the slot count M
+ *      goes to a DEVICE word (no read-back, no synchronisation; same dst_index as
+ *      vings_splat_compact_plan)
+ *   3. vings_surfel_project_backward_pack  the per-splat backward of the view with the weighted
+ *      gradients and s0 written into the chunked buffer: slot s is in chunk c = s / chunk_rows,
+ *      packed[(c*14 + column)*chunk_rows + (s - c*chunk_rows)], columns {g_xyz 3, g_rgb 3,
+ *      g_opacity 1, g_scaling 2, g_rotation 4, s0}; rows_of_slot[s] = row; record keys folded
+ *      as in vings_surfel_project_backward_finish.  packed must hold
+ *      14 * chunk_rows * ceil(M / chunk_rows) floats.
+ *   4. per chunk, after its SUM all-reduce: vings_splat_exchange_step(n_slots of the chunk,
+ *      chunk_rows, chunk, rows_of_slot + first slot of the chunk, ...) adds the summed s0 to
+ *      global_scores[:,0] (clamped to [0,1e4]) and local_scores[:,0] and applies the
+ *      row-masked Adam update of vings_sparse_adam to the 13 parameters of every slot whose
+ *      splat is not stable (params / exp_avgs / exp_avg_sqs / lrs: HOST arrays of 5 entries
+ *      in the order xyz, rgb, opacity, scaling, rotation).
+ */
+int vings_splat_exchange_columns(void);
+int vings_splat_touched(int N, const int32_t* radii, uint8_t* touched, void* stream);
+int vings_splat_compact_plan_device(int N, const uint8_t* keep, int32_t* dst_index,
+                                    void* workspace, size_t workspace_bytes,
+                                    int64_t* n_keep_device, void* stream);
+int vings_surfel_project_backward_pack(
+    int N, int H, int W, float scale_modifier, const float* means3D, const float* scales,
+    const float* rotations, const float* viewmatrix, const float* projmatrix, const int32_t* radii,
+    const float* dgeom, const float* opacities, const float* raw_rotation,
+    const float* global_scores, int64_t this_kf, float* scores_grad, float* packed,
+    int64_t* record_keys, const int32_t* slot_of_row, int32_t* rows_of_slot, int chunk_rows,
+    void* stream);
+int vings_splat_exchange_step(int n_slots, int chunk_rows, const float* chunk,
+                              const int32_t* rows, float* const* params_host,
+                              float* const* exp_avgs_host, float* const* exp_avg_sqs_host,
+                              const float* lrs_host, float b1, float b2, float eps,
+                              const uint8_t* stable_mask, float* global_scores,
+                              float* local_scores, void* stream);
+
+/* ------------------------------------------------------------------------
  * Forward-only importance of every splat in one view: importance[i] (+)= sum over pixels of
  * the blend weight alpha*T, i.e. the value the backward pass leaves in scores.grad[:,0]
  * (it does not depend on the upstream gradient).  Serves the scoring passes that the

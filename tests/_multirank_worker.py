@@ -26,8 +26,12 @@ def main():
     # c = b, except that it merges its record keys over the ranks BEFORE the map maintenance
     # below; b carries its unmerged keys through the prune and the append
     c = harness.SurfelMapper(raw, dev)
-    red = parallel.GradReducer(n, dev, world)
+    # d = b with the planar exchange (all N rows in one all-reduce) instead of the compact one
+    d = harness.SurfelMapper(raw, dev)
+    red = parallel.GradReducer(n, dev, world, n_chunks=3)
     red_c = parallel.GradReducer(n, dev, world)
+    red_d = parallel.GradReducer(n, dev, world, compact=False)
+    exchanged = []
     extra = {k: v[:300].clone() for k, v in synth.make_splats(600, W, H, n_views=2, seed=34).items()}
     for s in range(steps):
         k = s * world + rank                      # this rank's keyframe of the step
@@ -39,26 +43,29 @@ def main():
         radii, cur = a.backward_view(w2c, intr, gt)
         a.finish_view(radii, cur, k, red)
         b.fused_view(harness.view_settings(w2c, intr), intr, gt, w2c[:3, :3].cpu(), k, red)
+        exchanged.append(red.last_exchanged_rows)
         c.fused_view(harness.view_settings(w2c, intr), intr, gt, w2c[:3, :3].cpu(), k, red_c)
+        d.fused_view(harness.view_settings(w2c, intr), intr, gt, w2c[:3, :3].cpu(), k, red_d)
         if s == 0:
             a.sync_records(red)                    # blocking form after the first step ...
             b.sync_records(red)
             c.sync_records(red_c)
+            d.sync_records(red_d)
         if s == 1:
             # map maintenance between two view steps of a multi-rank job: every rank prunes the
             # same splats and appends the same new ones (the splat count changes twice)
             c.sync_records(red_c)
-            for m in (a, b, c):
+            for m in (a, b, c, d):
                 mask = (torch.arange(m.n, device=dev) % 9) == 4
                 maintenance.prune(m, mask)
                 maintenance.add_splats(m, extra)
                 assert m.n == n - int(mask.sum()) + 300
-    for m, r in ((a, red), (b, red), (c, red_c)):  # ... and the overlapped form at the end
+    for m, r in ((a, red), (b, red), (c, red_c), (d, red_d)):  # ... and the overlapped form at the end
         fin = m.sync_records(r, async_op=True)
         fin()
     torch.cuda.synchronize()
-    state = {"rank": rank}
-    for name, m in (("autograd", a), ("fused", b), ("fused_synced_first", c)):
+    state = {"rank": rank, "exchanged_rows": exchanged}
+    for name, m in (("autograd", a), ("fused", b), ("fused_synced_first", c), ("fused_planar", d)):
         state[name] = {k: m.params[k].detach().cpu() for k in m.NAMES}
         state[name]["global_scores"] = m.global_scores.cpu()
         state[name]["local_scores"] = m.local_scores.cpu()

@@ -1,7 +1,8 @@
-"""Two ranks of the sharded mapping loop on the GPU: replicas must stay bit-identical after
-every exchanged step, and the fused C-ABI view step must agree with the autograd-driven
-formulation of the same two-rank step.  The ranks share the test box's single GPU and
-exchange over gloo; on a multi-GPU node bench.py runs the same code over RCCL."""
+"""Two and four ranks of the sharded mapping loop on the GPU: replicas must stay bit-identical
+after every exchanged step, the fused C-ABI view step must agree with the autograd-driven
+formulation of the same step, and its compact exchange (touched rows only, in chunks) with
+its planar one.  The ranks share the test box's single GPU and exchange over gloo; on a
+multi-GPU node bench.py runs the same code over RCCL."""
 import os
 import socket
 import subprocess
@@ -20,20 +21,34 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_two_rank_view_steps(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_rank_view_steps(tmp_path, world):
     out = str(tmp_path / "state")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(HERE, "_multirank_worker.py"), out]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     s0 = torch.load(out + ".rank0.pt", weights_only=True)
-    s1 = torch.load(out + ".rank1.pt", weights_only=True)
     names = ("_xyz", "_rgb", "_opacity", "_scaling", "_rotation")
-    for impl in ("autograd", "fused", "fused_synced_first"):
-        for k in names + ("global_scores", "local_scores", "kf_id", "kf_max"):
-            assert torch.equal(s0[impl][k], s1[impl][k]), f"{impl}: replicas differ in {k}"
+    for r in range(1, world):
+        s1 = torch.load(out + f".rank{r}.pt", weights_only=True)
+        for impl in ("autograd", "fused", "fused_synced_first", "fused_planar"):
+            for k in names + ("global_scores", "local_scores", "kf_id", "kf_max"):
+                assert torch.equal(s0[impl][k], s1[impl][k]), f"{impl}: replicas 0 and {r} differ in {k}"
+        assert s1["exchanged_rows"] == s0["exchanged_rows"]
+    # the compact exchange moved the rows some rank saw, not the whole map
+    assert all(0 < m < 5300 for m in s0["exchanged_rows"]), s0["exchanged_rows"]
+    # compact against planar exchange of the same fused step (two runs of the blend backward:
+    # float atomics, so a tolerance)
+    for k in names:
+        ub = s0["fused"][k] - s0["raw"][k]
+        ud = s0["fused_planar"][k] - s0["raw"][k]
+        assert float((ub - ud).abs().max()) <= 2e-2 * float(ub.abs().max()), k
+    for k in ("global_scores", "local_scores", "kf_max"):
+        scale = float(s0["fused"][k].abs().max())
+        assert float((s0["fused"][k] - s0["fused_planar"][k]).abs().max()) <= 1e-4 * scale, k
     # Between the second and the third step every mapper was pruned and extended.  The record
     # keys a rank had not yet merged travelled with their splats: the mapper that merged them
     # before the maintenance ends with the same records and parameters, bit for bit.

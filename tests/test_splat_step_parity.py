@@ -229,6 +229,113 @@ def test_project_backward_finish_equals_the_two_calls(bookkeeping):
         assert not torch.equal(keys_a, keys0)
 
 
+@pytest.mark.parametrize("n_chunks,extra_touched", [(1, 0), (3, 0), (4, 60)])
+def test_compact_exchange_of_one_rank_equals_the_single_gpu_step(n_chunks, extra_touched):
+    """The compact multi-GPU tail (touched mask -> slot scan -> per-splat backward packed into
+    chunks -> per chunk: score records + Adam; record keys merged afterwards) fed with ONE
+    rank's blend-pass output, against the single-GPU tail on the same output
+    (vings_surfel_project_backward_finish with bookkeeping + SparseGaussianAdam.step):
+    parameters, both Adam moments and every score record bit-identical.  `extra_touched` rows
+    that this rank does not see are added to the union, as another rank's view would."""
+    from vings_mono_amd import parallel, surfel
+    dev = torch.device(DEV)
+    L = _lib.lib()
+    p = _lib.ptr
+    W, H, n = 160, 96, 4000
+    raw = {k: v.to(dev).contiguous() for k, v in synth.make_splats(n, W, H, n_views=2, seed=7).items()}
+    intr = synth.intrinsic_for(W, H)
+    w2c = torch.linalg.inv(synth.window_poses(2)[1]).to(dev)
+    act = synth.activate(raw)
+    opac, scales, rot = (act[k].contiguous() for k in ("opacities", "scales", "rotations"))
+    xyz, rgb = raw["_xyz"], raw["_rgb"]
+    st, aux = surfel.rasterize_forward(xyz, rgb, opac, scales, rot, harness.view_settings(w2c, intr))
+    g = torch.Generator(device="cpu").manual_seed(3)
+    g_color = torch.randn(3, H, W, generator=g).to(dev)
+    g_allmap = torch.randn(surfel.AUX_CHANNELS, H, W, generator=g).to(dev)
+    dgeom = surfel.blend_backward(st, aux, g_color, g_allmap)
+    stable = (torch.arange(n, device=dev) % 5 == 0)
+    stream = _lib.stream_ptr(dev)
+    lrs = {k + "_lr": v for k, v in zip(harness.SurfelMapper.NAMES, (1e-3, 2e-3, 3e-2, 4e-3, 1e-3))}
+
+    def mapper():
+        m = harness.SurfelMapper({k: v.clone() for k, v in raw.items()}, dev, lr=lrs)
+        gen = torch.Generator(device="cpu").manual_seed(11)
+        m.global_scores = (torch.rand(n, 2, generator=gen) * 3).to(dev)
+        m.local_scores = torch.rand(n, 2, generator=gen).to(dev)
+        m.globalkf_max_scores = (torch.rand(n, generator=gen) * 0.05).to(dev)
+        m.stable_mask = stable.clone()
+        for k in m.NAMES:                                    # moments of an earlier step
+            stt = m.optimizer._moments(m.params[k])
+            stt["exp_avg"].copy_(torch.randn(m.params[k].shape, generator=gen) * 1e-3)
+            stt["exp_avg_sq"].copy_(torch.rand(m.params[k].shape, generator=gen) * 1e-6)
+        return m
+
+    # single-GPU tail
+    a = mapper()
+    ga = [torch.zeros_like(a.params[k]) for k in a.NAMES]
+    for k, t in zip(a.NAMES, ga):
+        a.params[k].grad = t
+    vis = torch.empty(n, dtype=torch.uint8, device=dev)
+    _lib.check(L.vings_surfel_project_backward_finish(
+        n, H, W, 1.0, p(xyz), p(scales), p(rot), p(aux[0]), p(aux[1]), p(st.radii), p(dgeom),
+        p(opac), p(raw["_rotation"]), p(a.stable_mask.view(torch.uint8)), p(a.global_scores),
+        p(a.local_scores), p(a.globalkf_max_scores), p(a.globalkf_id), 5, 1, *[p(t) for t in ga],
+        p(vis), None, None, None, stream), "project_backward_finish")
+    unseen = torch.nonzero(st.radii <= 0).reshape(-1)[:extra_touched]
+    assert unseen.numel() == extra_touched
+    # a splat another rank sees takes the Adam step here too (with that rank's gradient; none
+    # in this test), unless it is stable
+    vis[unseen] = (~stable[unseen]).to(torch.uint8)
+    a.optimizer.step(vis, n)
+
+    # compact tail, the "all-reduce" being the identity
+    b = mapper()
+    touched = torch.empty(n, dtype=torch.uint8, device=dev)
+    _lib.check(L.vings_splat_touched(n, p(st.radii), p(touched), stream), "touched")
+    touched[unseen] = 1
+    slot = torch.empty(n, dtype=torch.int32, device=dev)
+    rows = torch.full((n,), -7, dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws_bytes = int(L.vings_splat_compact_workspace_bytes(n))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _lib.check(L.vings_splat_compact_plan_device(n, p(touched), p(slot), p(ws), ws_bytes, p(count),
+                                                 stream), "plan_device")
+    m = int(count.item())
+    assert m == int(touched.sum()) and m >= int((st.radii > 0).sum())
+    chunk_rows, used = parallel.chunk_layout(m, n_chunks)
+    assert used == -(-m // chunk_rows) and used <= n_chunks and chunk_rows % 256 == 0
+    cols = L.vings_splat_exchange_columns()
+    packed = torch.full((cols * chunk_rows * used,), float("nan"), device=dev)
+    keys = torch.zeros((n, 2), dtype=torch.int64, device=dev)
+    _lib.check(L.vings_surfel_project_backward_pack(
+        n, H, W, 1.0, p(xyz), p(scales), p(rot), p(aux[0]), p(aux[1]), p(st.radii), p(dgeom),
+        p(opac), p(raw["_rotation"]), p(b.global_scores), 5, None, p(packed), p(keys), p(slot),
+        p(rows), chunk_rows, stream), "project_backward_pack")
+    assert torch.equal(rows[:m].long(), torch.nonzero(touched).reshape(-1))
+    PP, MM, VV, LR, b1, b2, eps = b.optimizer.row_step_args(n, (3, 3, 1, 2, 4))
+    for k in range(used):
+        chunk = packed[k * cols * chunk_rows:(k + 1) * cols * chunk_rows]
+        first, cnt = k * chunk_rows, min(chunk_rows, m - k * chunk_rows)
+        _lib.check(L.vings_splat_exchange_step(
+            cnt, chunk_rows, p(chunk), rows.data_ptr() + 4 * first, PP, MM, VV, LR, b1, b2, eps,
+            p(b.stable_mask.view(torch.uint8)), p(b.global_scores), p(b.local_scores), stream),
+            "exchange_step")
+    _lib.check(L.vings_splat_merge_records(n, p(keys), p(b.local_scores), p(b.globalkf_max_scores),
+                                           p(b.globalkf_id), stream), "merge_records")
+    torch.cuda.synchronize()
+    assert int(vis.sum()) > 0
+    for k in a.NAMES:
+        assert not torch.equal(a.params[k].detach(), raw[k]), k
+        assert torch.equal(a.params[k].detach(), b.params[k].detach()), k
+        for mom in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(a.optimizer.state[a.params[k]][mom],
+                               b.optimizer.state[b.params[k]][mom]), (k, mom)
+    assert torch.equal(a.global_scores, b.global_scores)
+    assert torch.equal(a.local_scores, b.local_scores)
+    assert torch.equal(a.globalkf_max_scores, b.globalkf_max_scores)
+    assert torch.equal(a.globalkf_id, b.globalkf_id)
+
+
 def test_projection_with_inline_activation_equals_activate_then_project():
     """rasterize_forward(raw=...) (activations applied inside the projection kernel) against
     vings_splat_activate followed by the plain forward pass: activated arrays and every

@@ -60,6 +60,13 @@ _SIGNATURES = {
     "vings_splat_unpack_exchange": (_c.c_int, [_c.c_int] + [_P] * 10),
     "vings_splat_pack_columns": (_c.c_int, []),
     "vings_splat_merge_records": (_c.c_int, [_c.c_int] + [_P] * 5),
+    "vings_splat_exchange_columns": (_c.c_int, []),
+    "vings_splat_touched": (_c.c_int, [_c.c_int, _P, _P, _P]),
+    "vings_splat_compact_plan_device": (_c.c_int, [_c.c_int, _P, _P, _P, _c.c_size_t, _P, _P]),
+    "vings_surfel_project_backward_pack": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float] +
+                                           [_P] * 10 + [_c.c_int64] + [_P] * 5 + [_c.c_int, _P]),
+    "vings_splat_exchange_step": (_c.c_int, [_c.c_int, _c.c_int] + [_P] * 6 + [_c.c_float] * 3 +
+                                  [_P] * 4),
     "vings_depth_covariance": (_c.c_int, [_c.c_int] * 4 + [_P] * 8),
     "vings_upsample_maps": (_c.c_int, [_c.c_int] * 3 + [_P, _P, _c.c_int, _P, _P, _P]),
     "vings_package_workspace_bytes": (_c.c_size_t, [_c.c_int]),

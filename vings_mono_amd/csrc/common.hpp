@@ -135,4 +135,13 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
     return v;
 }
 
+// One element of the row-masked Adam step (no bias correction, no weight decay); shared by
+// every kernel that applies it so that they agree bit for bit.
+__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float lr,
+                                            float b1, float b2, float eps) {
+    m = b1 * m + (1.0f - b1) * g;
+    v = b2 * v + (1.0f - b2) * g * g;
+    p += -lr * m / (sqrtf(v) + eps);
+}
+
 }  // namespace vings

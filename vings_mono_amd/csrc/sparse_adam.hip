@@ -9,13 +9,6 @@
 
 namespace vings {
 
-__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float lr,
-                                            float b1, float b2, float eps) {
-    m = b1 * m + (1.0f - b1) * g;
-    v = b2 * v + (1.0f - b2) * g * g;
-    p += -lr * m / (sqrtf(v) + eps);
-}
-
 __global__ __launch_bounds__(256) void sparse_adam_kernel(
     float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ exp_avg,
     float* __restrict__ exp_avg_sq, const uint8_t* __restrict__ visible, float lr, float b1,

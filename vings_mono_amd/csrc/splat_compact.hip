@@ -138,6 +138,29 @@ extern "C" int vings_splat_compact_plan(int N, const uint8_t* keep, int32_t* dst
     return VINGS_OK;
 }
 
+extern "C" int vings_splat_compact_plan_device(int N, const uint8_t* keep, int32_t* dst_index,
+                                               void* workspace, size_t workspace_bytes,
+                                               int64_t* n_keep_device, void* stream) {
+    VINGS_REQUIRE(N >= 0 && n_keep_device, "sizes");
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) {
+        VINGS_CHECK_HIP(hipMemsetAsync(n_keep_device, 0, sizeof(int64_t), s));
+        return VINGS_OK;
+    }
+    VINGS_REQUIRE(keep && dst_index && workspace, "null pointer");
+    VINGS_REQUIRE(workspace_bytes >= vings_splat_compact_workspace_bytes(N), "workspace too small");
+    VINGS_REQUIRE(((uintptr_t)workspace & 3) == 0, "workspace must be 4-byte aligned");
+    uint32_t* counts = reinterpret_cast<uint32_t*>(workspace);
+    const int nb = cdiv(N, 256);
+    compact_count_kernel<<<nb, 256, 0, s>>>(N, keep, counts);
+    VINGS_LAUNCH_CHECK();
+    compact_scan_kernel<<<1, 1024, 0, s>>>(counts, nb, reinterpret_cast<long long*>(n_keep_device));
+    VINGS_LAUNCH_CHECK();
+    compact_index_kernel<<<nb, 256, 0, s>>>(N, keep, counts, dst_index);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}
+
 namespace {
 constexpr int kMaxDev = 64;
 std::mutex g_scratch_mu;

@@ -26,6 +26,13 @@ struct FinishArgs {
     // straight into the planar exchange buffer (packed[c * N + i], 15 columns) instead of g_*
     // and `visible`, and the record keys are folded into record_keys [N,2] (see splat_step.hip).
     float* packed; long long* record_keys; int N;
+    // Compact form of the same: only the rows some rank touched (slot_of_row[i] >= 0, the
+    // order-preserving rank of row i among them) are exchanged.  Slot s lives in chunk
+    // c = s / chunk_rows at packed[(c * 14 + column) * chunk_rows + (s - c * chunk_rows)]: 14
+    // columns, planar inside a chunk, chunks back to back, so that each chunk is one
+    // contiguous all-reduce; the visibility flag needs no column (a row is visible somewhere
+    // exactly when it has a slot and is not stable).  rows_of_slot[s] = i is written here too.
+    const int32_t* slot_of_row; int32_t* rows_of_slot; int chunk_rows;
 };
 
 // dm / dc / dop / ds / g: gradients w.r.t. the position, colour and the ACTIVATED opacity,
@@ -63,6 +70,25 @@ __device__ __forceinline__ void splat_finish(int i, const FinishArgs& a, const f
     } else {
         const float k = 1e12f * w;
         out = make_float4(g.x * k, g.y * k, g.z * k, g.w * k);
+    }
+    if (a.packed && a.slot_of_row) {
+        const int slot = a.slot_of_row[i];
+        if (slot < 0) return;                      // no rank touched this splat in this step
+        const int c = slot / a.chunk_rows;
+        float* __restrict__ dst = a.packed + ((size_t)c * 14 * a.chunk_rows + (slot - c * a.chunk_rows));
+        const float v[14] = {dm[0] * w, dm[1] * w, dm[2] * w, dc[0] * w, dc[1] * w, dc[2] * w, g_op,
+                             g_sc.x, g_sc.y, out.x, out.y, out.z, out.w, s0};
+#pragma unroll
+        for (int k = 0; k < 14; ++k) dst[(size_t)k * a.chunk_rows] = v[k];
+        a.rows_of_slot[slot] = i;
+        if (a.radii[i] > 0) {                      // a splat this rank did not touch has no scores
+            const long long b0 = (long long)__float_as_uint(fmaxf(s0, 0.f));
+            const long long b1 = (long long)__float_as_uint(fmaxf(s1, 0.f));
+            const long long k0 = (b0 << 32) | ((long long)a.this_kf & 0xFFFFFFFFll);
+            a.record_keys[2 * i] = max(a.record_keys[2 * i], k0);
+            a.record_keys[2 * i + 1] = max(a.record_keys[2 * i + 1], b1);
+        }
+        return;
     }
     if (a.packed) {
         const float v[15] = {dm[0] * w, dm[1] * w, dm[2] * w, dc[0] * w, dc[1] * w, dc[2] * w, g_op,

@@ -106,6 +106,56 @@ __global__ __launch_bounds__(256) void splat_merge_records_kernel(int N, long lo
     if (kf_max_scores[i] < best) { kf_max_scores[i] = best; kf_id[i] = (int64_t)(k0 & 0xFFFFFFFFll); }
 }
 
+
+// ---- compact exchange: one chunk of summed rows -> score records + Adam ----
+// After the all-reduce of a chunk (layout in splat_finish.hpp) one lane per slot adds the
+// summed importance score to the records and, unless the splat is stable, applies the Adam
+// step to its 13 parameters straight from the summed gradients: the unpack into the gradient
+// arrays and the masked Adam pass over all N rows of the planar form fall away.  Slots are in
+// row order, so the row accesses of a wave stay within a few cache lines.
+struct StepGroups {
+    float* p[5]; float* m[5]; float* v[5];   // xyz 3, rgb 3, opacity 1, scaling 2, rotation 4
+    float lr[5];
+};
+
+template <int M>
+__device__ __forceinline__ void adam_row(float* __restrict__ P, float* __restrict__ Mo,
+                                         float* __restrict__ Vo, int i, const float* g, float lr,
+                                         float b1, float b2, float eps) {
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        float p = P[(size_t)M * i + k], m = Mo[(size_t)M * i + k], v = Vo[(size_t)M * i + k];
+        adam_update(p, g[k], m, v, lr, b1, b2, eps);
+        P[(size_t)M * i + k] = p; Mo[(size_t)M * i + k] = m; Vo[(size_t)M * i + k] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void splat_exchange_step_kernel(
+    int n_slots, int chunk_rows, const float* __restrict__ chunk, const int32_t* __restrict__ rows,
+    StepGroups G, float b1, float b2, float eps, const uint8_t* __restrict__ stable_mask,
+    float* __restrict__ global_scores, float* __restrict__ local_scores) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_slots) return;
+    float v[14];
+#pragma unroll
+    for (int c = 0; c < 14; ++c) v[c] = chunk[(size_t)c * chunk_rows + j];
+    const int i = rows[j];
+    local_scores[2 * i] += v[13];
+    global_scores[2 * i] = fminf(fmaxf(global_scores[2 * i] + v[13], 0.f), 1e4f);
+    if (stable_mask && stable_mask[i]) return;
+    adam_row<3>(G.p[0], G.m[0], G.v[0], i, v + 0, G.lr[0], b1, b2, eps);
+    adam_row<3>(G.p[1], G.m[1], G.v[1], i, v + 3, G.lr[1], b1, b2, eps);
+    adam_row<1>(G.p[2], G.m[2], G.v[2], i, v + 6, G.lr[2], b1, b2, eps);
+    adam_row<2>(G.p[3], G.m[3], G.v[3], i, v + 7, G.lr[3], b1, b2, eps);
+    adam_row<4>(G.p[4], G.m[4], G.v[4], i, v + 9, G.lr[4], b1, b2, eps);
+}
+
+__global__ __launch_bounds__(256) void splat_touched_kernel(int N, const int* __restrict__ radii,
+                                                            uint8_t* __restrict__ touched) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < N) touched[i] = radii[i] > 0 ? 1 : 0;
+}
+
 }  // namespace vings
 
 using namespace vings;
@@ -220,6 +270,42 @@ extern "C" int vings_splat_merge_records(int N, int64_t* record_keys, float* loc
     ProfScope prof(PROF_GLUE, (hipStream_t)stream);
     splat_merge_records_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(
         N, reinterpret_cast<long long*>(record_keys), local_scores, kf_max_scores, kf_id);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}
+
+extern "C" int vings_splat_exchange_columns(void) { return 14; }
+
+extern "C" int vings_splat_touched(int N, const int32_t* radii, uint8_t* touched, void* stream) {
+    VINGS_REQUIRE(N >= 0, "sizes");
+    if (N == 0) return VINGS_OK;
+    VINGS_REQUIRE(radii && touched, "null pointer");
+    ProfScope prof(PROF_GLUE, (hipStream_t)stream);
+    splat_touched_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(N, radii, touched);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}
+
+extern "C" int vings_splat_exchange_step(int n_slots, int chunk_rows, const float* chunk,
+                                         const int32_t* rows, float* const* params_host,
+                                         float* const* exp_avgs_host,
+                                         float* const* exp_avg_sqs_host, const float* lrs_host,
+                                         float b1, float b2, float eps, const uint8_t* stable_mask,
+                                         float* global_scores, float* local_scores, void* stream) {
+    VINGS_REQUIRE(n_slots >= 0 && chunk_rows >= n_slots, "a chunk holds at most chunk_rows slots");
+    if (n_slots == 0) return VINGS_OK;
+    VINGS_REQUIRE(chunk && rows && params_host && exp_avgs_host && exp_avg_sqs_host && lrs_host &&
+                      global_scores && local_scores,
+                  "null pointer");
+    StepGroups G;
+    for (int g = 0; g < 5; ++g) {
+        VINGS_REQUIRE(params_host[g] && exp_avgs_host[g] && exp_avg_sqs_host[g], "group pointers");
+        G.p[g] = params_host[g]; G.m[g] = exp_avgs_host[g]; G.v[g] = exp_avg_sqs_host[g];
+        G.lr[g] = lrs_host[g];
+    }
+    ProfScope prof(PROF_ADAM, (hipStream_t)stream);
+    splat_exchange_step_kernel<<<cdiv(n_slots, 256), 256, 0, (hipStream_t)stream>>>(
+        n_slots, chunk_rows, chunk, rows, G, b1, b2, eps, stable_mask, global_scores, local_scores);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }

@@ -687,14 +687,15 @@ extern "C" int vings_surfel_project_backward(int N, int H, int W, float scale_mo
     return VINGS_OK;
 }
 
-extern "C" int vings_surfel_project_backward_finish(
+static int project_backward_finish(
     int N, int H, int W, float scale_modifier, const float* means3D, const float* scales,
     const float* rotations, const float* viewmatrix, const float* projmatrix, const int32_t* radii,
     const float* dgeom, const float* opacities, const float* raw_rotation,
     const uint8_t* stable_mask, float* global_scores, float* local_scores, float* kf_max_scores,
     int64_t* kf_id, int64_t this_kf, int bookkeeping, float* g_xyz, float* g_rgb, float* g_opacity,
     float* g_scaling, float* g_rotation, uint8_t* visible, float* scores_grad, float* packed,
-    int64_t* record_keys, void* stream) {
+    int64_t* record_keys, const int32_t* slot_of_row, int32_t* rows_of_slot, int chunk_rows,
+    void* stream) {
     VINGS_REQUIRE(N >= 0 && H > 0 && W > 0, "sizes");
     if (N == 0) return VINGS_OK;
     VINGS_REQUIRE(means3D && scales && rotations && viewmatrix && projmatrix && radii && dgeom &&
@@ -717,10 +718,44 @@ extern "C" int vings_surfel_project_backward_finish(
     a.g_rotation = g_rotation; a.visible = visible; a.this_kf = this_kf;
     a.bookkeeping = bookkeeping;
     a.packed = packed; a.record_keys = reinterpret_cast<long long*>(record_keys); a.N = N;
+    a.slot_of_row = slot_of_row; a.rows_of_slot = rows_of_slot; a.chunk_rows = chunk_rows;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PROF_PROJECT_BWD, s);
     project_bwd_finish_kernel<<<cdiv(N, 256), 256, 0, s>>>(
         N, H, W, scale_modifier, means3D, rotations, viewmatrix, projmatrix, dgeom, a, scores_grad);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
+}
+
+extern "C" int vings_surfel_project_backward_finish(
+    int N, int H, int W, float scale_modifier, const float* means3D, const float* scales,
+    const float* rotations, const float* viewmatrix, const float* projmatrix, const int32_t* radii,
+    const float* dgeom, const float* opacities, const float* raw_rotation,
+    const uint8_t* stable_mask, float* global_scores, float* local_scores, float* kf_max_scores,
+    int64_t* kf_id, int64_t this_kf, int bookkeeping, float* g_xyz, float* g_rgb, float* g_opacity,
+    float* g_scaling, float* g_rotation, uint8_t* visible, float* scores_grad, float* packed,
+    int64_t* record_keys, void* stream) {
+    return project_backward_finish(N, H, W, scale_modifier, means3D, scales, rotations, viewmatrix,
+                                   projmatrix, radii, dgeom, opacities, raw_rotation, stable_mask,
+                                   global_scores, local_scores, kf_max_scores, kf_id, this_kf,
+                                   bookkeeping, g_xyz, g_rgb, g_opacity, g_scaling, g_rotation,
+                                   visible, scores_grad, packed, record_keys, nullptr, nullptr, 0,
+                                   stream);
+}
+
+extern "C" int vings_surfel_project_backward_pack(
+    int N, int H, int W, float scale_modifier, const float* means3D, const float* scales,
+    const float* rotations, const float* viewmatrix, const float* projmatrix, const int32_t* radii,
+    const float* dgeom, const float* opacities, const float* raw_rotation,
+    const float* global_scores, int64_t this_kf, float* scores_grad, float* packed,
+    int64_t* record_keys, const int32_t* slot_of_row, int32_t* rows_of_slot, int chunk_rows,
+    void* stream) {
+    VINGS_REQUIRE(packed && record_keys && slot_of_row && rows_of_slot && chunk_rows > 0,
+                  "the compact exchange form needs its buffer, the slot tables and the chunk length");
+    return project_backward_finish(N, H, W, scale_modifier, means3D, scales, rotations, viewmatrix,
+                                   projmatrix, radii, dgeom, opacities, raw_rotation, nullptr,
+                                   const_cast<float*>(global_scores), nullptr, nullptr, nullptr,
+                                   this_kf, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                   scores_grad, packed, record_keys, slot_of_row, rows_of_slot,
+                                   chunk_rows, stream);
 }

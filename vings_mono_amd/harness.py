@@ -346,37 +346,75 @@ class SurfelMapper:
                 xyz, rgb, fb["opac"], fb["scales"], fb["rot"], settings,
                 raw=(P["_opacity"].detach(), P["_scaling"].detach(), P["_rotation"].detach()),
                 dgeom=dgeom)
+            single = reducer is None or reducer.world == 1
+            compact = not single and reducer.compact
+            if compact:
+                # which splats does some rank touch in this step?  Known from the projection
+                # on; agreed between the ranks on a side stream while this one goes on
+                reducer.start_union(st.radii)
             loss_vec, d_rgb, d_allmap = mapping_loss_hip(st.color, st.allmap, gt, Rw2c_host, intr,
                                                          self.loss_weights)
-            single = reducer is None or reducer.world == 1
             g = fb["grads"]
             view, proj = aux[0], aux[1]
             surfel.blend_backward(st, aux, d_rgb, d_allmap, dgeom=dgeom)
-            # per-splat backward + chain rule through the activations + score weighting +
-            # bookkeeping in one launch
-            _lib.check(L.vings_surfel_project_backward_finish(
-                n, st.H, st.W, 1.0, ptr(xyz), ptr(fb["scales"]), ptr(fb["rot"]), ptr(view),
-                ptr(proj), ptr(st.radii), ptr(dgeom), ptr(fb["opac"]), ptr(P["_rotation"]),
-                ptr(self.stable_mask.view(torch.uint8)), ptr(self.global_scores),
-                ptr(self.local_scores), ptr(self.globalkf_max_scores), ptr(self.globalkf_id),
-                int(kf_id), 1 if single else 0, ptr(g["_xyz"]), ptr(g["_rgb"]), ptr(g["_opacity"]),
-                ptr(g["_scaling"]), ptr(g["_rotation"]), ptr(fb["vis"]), None,
-                None if single else ptr(reducer.fbuf),
-                None if single else ptr(self._record_keys()), stream),
-                "vings_surfel_project_backward_finish")
-            vis = fb["vis"]
-            if not single:
-                # (packed by the kernel above) -> SUM all-reduce over the replicas -> unpack
-                grad_ptrs = [ptr(g[k]) for k in self.NAMES]
-                reducer.all_reduce_packed()
-                _lib.check(L.vings_splat_unpack_exchange(
-                    n, ptr(reducer.fbuf), ptr(self.global_scores), ptr(self.local_scores),
-                    *grad_ptrs, ptr(vis), stream), "vings_splat_unpack_exchange")
-            self.optimizer.step(vis, n)
+            if compact:
+                self._exchange_compact(L, reducer, st, xyz, fb, view, proj, dgeom, kf_id, stream)
+            else:
+                # per-splat backward + chain rule through the activations + score weighting +
+                # bookkeeping in one launch
+                _lib.check(L.vings_surfel_project_backward_finish(
+                    n, st.H, st.W, 1.0, ptr(xyz), ptr(fb["scales"]), ptr(fb["rot"]), ptr(view),
+                    ptr(proj), ptr(st.radii), ptr(dgeom), ptr(fb["opac"]), ptr(P["_rotation"]),
+                    ptr(self.stable_mask.view(torch.uint8)), ptr(self.global_scores),
+                    ptr(self.local_scores), ptr(self.globalkf_max_scores), ptr(self.globalkf_id),
+                    int(kf_id), 1 if single else 0, ptr(g["_xyz"]), ptr(g["_rgb"]),
+                    ptr(g["_opacity"]), ptr(g["_scaling"]), ptr(g["_rotation"]), ptr(fb["vis"]), None,
+                    None if single else ptr(reducer.fbuf),
+                    None if single else ptr(self._record_keys()), stream),
+                    "vings_surfel_project_backward_finish")
+                vis = fb["vis"]
+                if not single:
+                    # (packed by the kernel above) -> SUM all-reduce over the replicas -> unpack
+                    grad_ptrs = [ptr(g[k]) for k in self.NAMES]
+                    reducer.all_reduce_packed()
+                    _lib.check(L.vings_splat_unpack_exchange(
+                        n, ptr(reducer.fbuf), ptr(self.global_scores), ptr(self.local_scores),
+                        *grad_ptrs, ptr(vis), stream), "vings_splat_unpack_exchange")
+                self.optimizer.step(vis, n)
         self.last_loss = loss_vec[0]
         self.last_loss_terms = loss_vec
         self._last_radii = st.radii
         return loss_vec
+
+    _WIDTHS = (3, 3, 1, 2, 4)
+
+    def _exchange_compact(self, L, reducer, st, xyz, fb, view, proj, dgeom, kf_id, stream):
+        """The multi-GPU tail of the fused view step in its compact form: the per-splat
+        backward writes the weighted gradients and the importance score of the rows some rank
+        touched into the chunked exchange buffer; every chunk is summed over the ranks and
+        then applied (score records + Adam on its rows) while the next one is being reduced."""
+        from . import _lib
+        ptr, n, P = _lib.ptr, self.n, self.params
+        m, chunk_rows = reducer.finish_union()
+        if m == 0:
+            return
+        cx = reducer._cx
+        _lib.check(L.vings_surfel_project_backward_pack(
+            n, st.H, st.W, 1.0, ptr(xyz), ptr(fb["scales"]), ptr(fb["rot"]), ptr(view), ptr(proj),
+            ptr(st.radii), ptr(dgeom), ptr(fb["opac"]), ptr(P["_rotation"]),
+            ptr(self.global_scores), int(kf_id), None, ptr(cx["packed"]),
+            ptr(self._record_keys()), ptr(cx["slot"]), ptr(cx["rows"]), chunk_rows, stream),
+            "vings_surfel_project_backward_pack")
+        PP, MM, VV, LR, b1, b2, eps = self.optimizer.row_step_args(n, self._WIDTHS)
+        stable = ptr(self.stable_mask.view(torch.uint8))
+        rows_base, gs, ls = cx["rows"].data_ptr(), ptr(self.global_scores), ptr(self.local_scores)
+
+        def apply(chunk, first_slot, n_slots):
+            _lib.check(L.vings_splat_exchange_step(
+                n_slots, chunk_rows, ptr(chunk), rows_base + 4 * first_slot, PP, MM, VV, LR,
+                b1, b2, eps, stable, gs, ls, stream), "vings_splat_exchange_step")
+
+        reducer.exchange_chunks(m, chunk_rows, apply)
 
     def train_view(self, c2w, intr, gt, kf_id=0, reducer=None):
         """One iteration of the reference's hot loop (gaussian_base.py:353-404)."""

@@ -4,11 +4,16 @@ replica per GPU, the keyframes of a window dealt out over the ranks.
 The reference is single-GPU (every config sets device.tracker = device.mapper =
 cuda:0, e.g. /root/reference/configs/hierarchical/smallcity.yaml:11-13), so
 this exchange step has no counterpart there.  Per optimisation step every
-rank renders and back-propagates its own view, then one collective keeps the
-replicas bit-identical:
+rank renders and back-propagates its own view, then the per-splat sums over
+the ranks of the 13 score-weighted parameter gradients and of the view's
+importance score keep the replicas bit-identical.  Two forms (`GradReducer`):
 
-  SUM  float32 [15,N] (planar): 13 score-weighted parameter gradients, the
-       importance score of the view and the visibility flag
+  planar   SUM of float32 [15,N] (13 gradients, score, visibility flag) in one
+           all-reduce over all N splats
+  compact  MAX of the uint8 [N] "touched" mask (known after the projection,
+           reduced on a side stream under the rest of the view), then SUM of
+           14 floats for the touched rows only, in chunks; chunk k is applied
+           (scores + Adam) while chunk k+1 is being reduced
 
 The two record maxima that no view step reads (best keyframe per splat, error
 score) stay rank-local between merges: every view folds
@@ -48,20 +53,128 @@ def shard_views(n_views, world, rank):
     return list(range(rank * per, min(n_views, (rank + 1) * per)))
 
 
+EXCHANGE_COLUMNS = 14      # the compact form: 13 gradients + importance score
+CHUNK_ALIGN = 256
+
+
+def chunk_layout(m, n_chunks):
+    """(chunk_rows, chunks in use) for m exchanged rows: equal chunks of a multiple of 256 rows,
+    the last one partly filled.  Chunk k is the contiguous float range
+    [k * 14 * chunk_rows, (k + 1) * 14 * chunk_rows) of the exchange buffer."""
+    per = -(-max(m, 1) // max(n_chunks, 1))
+    chunk_rows = -(-per // CHUNK_ALIGN) * CHUNK_ALIGN
+    return chunk_rows, -(-m // chunk_rows)
+
+
 class GradReducer:
-    def __init__(self, n, device, world, group=None):
+    """Exchange state of one mapper.  Two forms:
+
+    planar   `fbuf` [15,N], one SUM all-reduce per view over all N rows (`reduce`,
+             `all_reduce_packed`): what the autograd-driven view step uses.
+    compact  only the rows some rank touched in this step travel, in `n_chunks` contiguous
+             chunks, and chunk k is applied (scores + Adam) while chunk k+1 is still being
+             reduced (`start_union` / `finish_union` / `exchange_chunks`): what the fused view
+             step uses.  The set of touched rows is known right after the forward projection,
+             so its MAX all-reduce and the slot scan run on a side stream under the rest of the
+             view; by the time the backward pass has been queued the host has the row count.
+    """
+
+    def __init__(self, n, device, world, group=None, n_chunks=4, compact=True):
         self.n, self.world, self.group = n, world, group
-        if world > 1:
-            self.fbuf = torch.zeros((PACK_WIDTH, n), dtype=torch.float32, device=device)
+        self.device = torch.device(device)
+        self.n_chunks, self.compact = int(n_chunks), bool(compact)
+        self._fbuf = None
+        self._cx = None
+        self.last_exchanged_rows = None
+
+    @property
+    def fbuf(self):
+        if self._fbuf is None and self.world > 1:
+            self._fbuf = torch.zeros((PACK_WIDTH, self.n), dtype=torch.float32, device=self.device)
+        return self._fbuf
 
     def resize(self, n):
-        """The splat count changed (pruning, new keyframe): a fresh exchange buffer.  Nothing
-        of the old one is kept; it only lives from the pack to the unpack of one view."""
+        """The splat count changed (pruning, new keyframe): fresh exchange buffers.  Nothing
+        of the old ones is kept; they only live from the pack to the unpack of one view."""
         if n != self.n:
             self.n = n
-            if self.world > 1:
-                self.fbuf = torch.zeros((PACK_WIDTH, n), dtype=torch.float32,
-                                        device=self.fbuf.device)
+            self._fbuf = None
+            self._cx = None
+
+    # ------------------------------------------------------------------ compact form
+    def _compact_state(self):
+        if self._cx is None:
+            from . import _lib
+            n, dev = self.n, self.device
+            ws_bytes = int(_lib.lib().vings_splat_compact_workspace_bytes(n))
+            cx = {
+                "touched": torch.zeros(max(n, 1), dtype=torch.uint8, device=dev),
+                "slot": torch.empty(max(n, 1), dtype=torch.int32, device=dev),
+                "rows": torch.empty(max(n, 1), dtype=torch.int32, device=dev),
+                "count_dev": torch.zeros(1, dtype=torch.int64, device=dev),
+                "ws": torch.empty(ws_bytes, dtype=torch.uint8, device=dev), "ws_bytes": ws_bytes,
+                # every chunk may carry up to CHUNK_ALIGN - 1 unused rows
+                "packed": torch.zeros(EXCHANGE_COLUMNS * (n + self.n_chunks * CHUNK_ALIGN),
+                                      dtype=torch.float32, device=dev),
+            }
+            if dev.type == "cuda":
+                cx["count_host"] = torch.zeros(1, dtype=torch.int64).pin_memory()
+                cx["side"] = torch.cuda.Stream(device=dev)
+                cx["ev_fwd"] = torch.cuda.Event()
+                cx["ev_plan"] = torch.cuda.Event()
+            self._cx = cx
+        return self._cx
+
+    def start_union(self, radii):
+        """Queued right after the forward projection of the view (radii [N] int32, on the
+        current stream): touched = radii > 0, MAX over the ranks, slot scan, row count to the
+        host, all on a side stream.  Returns at once."""
+        import torch.distributed as dist
+        from . import _lib
+        L, cx, n = _lib.lib(), self._compact_state(), self.n
+        main = torch.cuda.current_stream(self.device)
+        _lib.check(L.vings_splat_touched(n, _lib.ptr(radii), _lib.ptr(cx["touched"]),
+                                         main.cuda_stream), "vings_splat_touched")
+        cx["ev_fwd"].record(main)
+        side = cx["side"]
+        with torch.cuda.stream(side):
+            side.wait_event(cx["ev_fwd"])
+            self._all_reduce(cx["touched"], dist.ReduceOp.MAX)
+            _lib.check(L.vings_splat_compact_plan_device(
+                n, _lib.ptr(cx["touched"]), _lib.ptr(cx["slot"]), _lib.ptr(cx["ws"]),
+                cx["ws_bytes"], _lib.ptr(cx["count_dev"]), side.cuda_stream),
+                "vings_splat_compact_plan_device")
+            cx["count_host"].copy_(cx["count_dev"], non_blocking=True)
+            cx["ev_plan"].record(side)
+
+    def finish_union(self):
+        """(rows to exchange, chunk_rows).  The host waits for the scan started by
+        `start_union` (long finished when this is called after the backward pass has been
+        queued); the current stream is ordered after it."""
+        cx = self._cx
+        cx["ev_plan"].synchronize()
+        torch.cuda.current_stream(self.device).wait_event(cx["ev_plan"])
+        m = int(cx["count_host"][0])
+        self.last_exchanged_rows = m
+        chunk_rows, _ = chunk_layout(m, self.n_chunks)
+        return m, chunk_rows
+
+    def exchange_chunks(self, m, chunk_rows, apply):
+        """SUM all-reduce of every chunk in use, all started at once (they run one after the
+        other on the collective's stream); `apply(chunk, first_slot, n_slots)` is called for
+        chunk k once the current stream is ordered after its all-reduce, i.e. the kernels it
+        launches run while chunk k+1 is still in flight."""
+        import torch.distributed as dist
+        cx = self._compact_state()
+        per = EXCHANGE_COLUMNS * chunk_rows
+        n_used = -(-m // chunk_rows)
+        chunks = [cx["packed"][k * per:(k + 1) * per] for k in range(n_used)]
+        works = [self._all_reduce(c, dist.ReduceOp.SUM, async_op=True) for c in chunks]
+        for k, (c, w) in enumerate(zip(chunks, works)):
+            w.wait()
+            apply(c, k * chunk_rows, min(chunk_rows, m - k * chunk_rows))
+
+    # ------------------------------------------------------------------ collectives
 
     class _Done:
         """Handle of a collective that has already completed."""
@@ -70,10 +183,17 @@ class GradReducer:
 
     def _all_reduce(self, t, op, async_op=False):
         """RCCL reduces device tensors in place on its own stream, ordered after the current
-        one.  gloo works on host memory: a device tensor is staged through the host here, in
-        the calling thread (its own staging of device tensors, done from a worker thread, was
-        seen to stall the GPU queue of a process for good when several processes share one
-        card, which is how the tests run two ranks on a one-GPU box)."""
+        one.  gloo works on host memory, and a device tensor is staged through the host HERE,
+        in the calling thread, not handed to gloo: torch's gloo backend stages a device tensor
+        itself (pinned buffer + asynchronous copy on a pool stream, set up inside
+        `all_reduce`), and with two processes on one GPU that call never returns, in either
+        rank, once the tensor is larger than a few hundred KB and the caller's stream still
+        has kernels queued when it is made (tools/gloo_probe.py reproduces it with plain
+        torch and no kernel of this library: `busy 100000` hangs, `idle` passes up to 60 MB).
+        `t.cpu()` is a synchronous copy on the current stream: it drains the queue first, so
+        gloo is only ever entered with nothing of this rank pending on the GPU and sees host
+        memory, which is the case that passes at every size.  Only the test rig (several ranks
+        on the one GPU of the test box) takes this branch."""
         import torch.distributed as dist
         if t.is_cuda and dist.get_backend(self.group) == "gloo":
             h = t.cpu()                       # waits for the kernels that produced t

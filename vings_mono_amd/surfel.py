@@ -338,6 +338,41 @@ class SparseGaussianAdam(torch.optim.Adam):
     def __init__(self, params, lr, eps):
         super().__init__(params=params, lr=lr, eps=eps)
 
+    def _moments(self, p):
+        state = self.state[p]
+        if len(state) == 0:
+            state["step"] = torch.tensor(0.0, dtype=torch.float32)
+            state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return state
+
+    @torch.no_grad()
+    def row_step_args(self, N, widths):
+        """Host pointer tables of the parameter groups, in group order, for a kernel that
+        applies this optimiser's update row by row itself (vings_splat_exchange_step):
+        (params, exp_avgs, exp_avg_sqs, lrs, b1, b2, eps).  `widths` are the row widths the
+        kernel assumes; all groups must share one (b1, b2, eps)."""
+        groups = self.param_groups
+        if len(groups) != len(widths):
+            raise _lib.VingsError(f"{len(widths)} parameter groups expected, {len(groups)} found")
+        keys = {(float(g["eps"]),) + tuple(float(b) for b in g.get("betas", (0.9, 0.999)))
+                for g in groups}
+        if len(keys) != 1:
+            raise _lib.VingsError("the parameter groups differ in eps / betas")
+        eps, b1, b2 = next(iter(keys))
+        ps, ms, vs, lrs = [], [], [], []
+        for g, width in zip(groups, widths):
+            (p,) = g["params"]
+            _lib.require_gpu_tensor(p, "param", torch.float32)
+            if p.numel() != N * width or not p.is_contiguous():
+                raise _lib.VingsError(f"group {g.get('name')}: expected a dense [{N},{width}] array")
+            st = self._moments(p)
+            ps.append(ptr(p)); ms.append(ptr(st["exp_avg"])); vs.append(ptr(st["exp_avg_sq"]))
+            lrs.append(float(g["lr"]))
+        n = len(widths)
+        return ((ctypes.c_void_p * n)(*ps), (ctypes.c_void_p * n)(*ms), (ctypes.c_void_p * n)(*vs),
+                (ctypes.c_float * n)(*lrs), b1, b2, eps)
+
     @torch.no_grad()
     def step(self, visibility, N):
         L = _lib.lib()
@@ -353,11 +388,7 @@ class SparseGaussianAdam(torch.optim.Adam):
             if p.grad is None:
                 continue
             _lib.require_gpu_tensor(p, "param", torch.float32)
-            state = self.state[p]
-            if len(state) == 0:
-                state["step"] = torch.tensor(0.0, dtype=torch.float32)
-                state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            state = self._moments(p)
             if p.numel() % N != 0:
                 raise _lib.VingsError("parameter size is not a multiple of N")
             b1, b2 = group.get("betas", (0.9, 0.999))
