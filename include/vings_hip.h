@@ -133,13 +133,14 @@ int vings_surfel_project_wait(int64_t* num_instances_host, uint32_t* depth_bits_
 size_t vings_surfel_bin_workspace_bytes(int64_t D);
 
 /* ------------------------------------------------------------------------
- * Stage 2: duplicate with keys (tile<<32 | depth bits), stable radix sort,
- * per-tile ranges.  Same reference call as above.
+ * Stage 2: duplicate with keys (tile<<32 | depth bits), order by (tile, depth, splat) - what
+ * a stable sort of the instances emitted in splat order gives -, per-tile ranges.  Same
+ * reference call as above.
  * out: keys_sorted[D](uint64) vals_sorted[D](uint32 splat index)
- *      ranges[T,2](uint32 begin,end) with T = ceil(W/16)*ceil(H/16)
+ *      ranges[T,2](uint32 begin,end; 8-byte aligned) with T = ceil(W/16)*ceil(H/16)
  * workspace: vings_surfel_bin_workspace_bytes(D) bytes, 256-byte aligned.
- * depth_bits_min/max: the range vings_surfel_project returned (the sort skips the key bits
- * that cannot differ); pass min > max (e.g. 1, 0) when it is not known.
+ * depth_bits_min/max: the range vings_surfel_project returned; not used any more (the radix
+ * passes run over the tile bits only, the depth order is made per tile in LDS), any values do.
  */
 int vings_surfel_bin(int N, int H, int W, int64_t D, uint32_t depth_bits_min,
                      uint32_t depth_bits_max, const float* depth, const int32_t* rect,
@@ -148,13 +149,13 @@ int vings_surfel_bin(int N, int H, int W, int64_t D, uint32_t depth_bits_min,
                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* Stage 2 launched before the host knows D: buffers (keys_sorted, vals_sorted, workspace)
- * hold D_capacity instances, low_bits_guess is the number of depth key bits assumed
- * (vings_surfel_bin_low_bits of an earlier view's range), and the kernels read the true
- * {depth_bits_min, depth_bits_max, D} from tail = block_prefix + 3*ceil(N/256) + 1 of the
- * projection on the same stream.  Nothing is written beyond the capacity.  The result equals
- * that of vings_surfel_bin iff D <= D_capacity and vings_surfel_bin_low_bits(true range) <=
- * low_bits_guess and yields the same number of sort passes; the caller checks this after
- * vings_surfel_project_wait and otherwise repeats the stage with vings_surfel_bin. */
+ * hold D_capacity instances and the kernels read the true D from tail[2],
+ * tail = block_prefix + 3*ceil(N/256) + 1 of the projection on the same stream.  Nothing is
+ * written beyond the capacity and no range reaches beyond it.  The result equals that of
+ * vings_surfel_bin iff D <= D_capacity; the caller checks this after
+ * vings_surfel_project_wait and otherwise repeats the stage with vings_surfel_bin.
+ * low_bits_guess is not used any more (vings_surfel_bin_low_bits: bits needed for the depth
+ * range, kept for callers that size things by it). */
 int vings_surfel_bin_low_bits(uint32_t depth_bits_min, uint32_t depth_bits_max);
 int vings_surfel_bin_speculative(int N, int H, int W, int64_t D_capacity, int low_bits_guess,
                                  const uint32_t* tail, const float* depth, const int32_t* rect,

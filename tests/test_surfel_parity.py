@@ -94,6 +94,7 @@ CASES = [
     dict(n=20000, W=320, H=240, scale_mul=4.0),        # long tile lists, saturating pixels
     dict(n=3000, W=200, H=120, scale_mul=0.05),        # sub-pixel splats: low-pass branch
     dict(n=1, W=64, H=48),
+    dict(n=30000, W=96, H=64, scale_mul=6.0),          # tile lists beyond one LDS sort (merge path)
     dict(n=200000, W=1920, H=1080),                    # BASELINE config 2
     dict(n=1000000, W=1920, H=1080, n_views=8, view_k=3),   # one view of BASELINE config 3
 ]
@@ -116,6 +117,11 @@ def test_forward_parity(case, oracle32, oracle64, tight):
         np.testing.assert_array_equal(st.keys.cpu().numpy().view(np.uint64)[:D], ref["keys"])
         np.testing.assert_array_equal(st.vals.cpu().numpy().view(np.uint32)[:D], ref["vals"])
         np.testing.assert_array_equal(st.ranges.cpu().numpy().view(np.uint32), ref["ranges"])
+        if sc["means3D"].shape[0] == 30000:
+            # this case is there for the depth sort's merge path: lists of more than three
+            # LDS-sized runs, and not a power-of-two number of them
+            longest = int((ref["ranges"][:, 1].astype(np.int64) - ref["ranges"][:, 0]).max())
+            assert longest > 3 * 2048 and (longest - 1) // 2048 + 1 not in (4, 8), longest
     else:
         # a subset of the reference's instance list, in the reference's order
         D = st.D

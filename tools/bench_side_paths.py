@@ -164,6 +164,56 @@ def main():
     jj = torch.arange(0, 8, device=dev).repeat(8)
     t = timed(lambda: dba_mod.frame_distance(prob.poses, prob.disps, prob.intr, ii, jj, 0.3), a.reps)
     res["frame_distance_64_pairs"] = entry(t)
+    # ---- on-the-fly correlation (no all-pairs volume) on the 1080p/8 grid ----------------------
+    E_, h1, w1, C = 48, H // 8, W // 8, 128
+    f1 = torch.randn(E_, h1, w1, C, device=dev)
+    total_f, total_b = 0.0, 0.0
+    for lvl in range(4):
+        h2, w2 = h1 >> lvl, w1 >> lvl
+        f2 = torch.randn(E_, h2, w2, C, device=dev)
+        xy = torch.stack(torch.meshgrid(torch.arange(w1, device=dev, dtype=torch.float32),
+                                        torch.arange(h1, device=dev, dtype=torch.float32),
+                                        indexing="xy"), -1)[None, None].repeat(E_, 1, 1, 1, 1)
+        c = ((xy + torch.randn_like(xy) * 3) / 2 ** lvl).contiguous()
+        total_f += timed(lambda: dba_mod.altcorr_forward(f1, f2, c, 3), a.reps)
+        g = torch.randn(E_, 1, 49, h1, w1, device=dev)
+        total_b += timed(lambda: dba_mod.altcorr_backward(f1, f2, c, g, 3), a.reps)
+        del f2
+    res["altcorr_forward_4_levels"] = entry(total_f, edges=E_, grid=[h1, w1], channels=C, radius=3,
+                                            flops=2 * 4 * E_ * h1 * w1 * 64 * C)
+    res["altcorr_backward_4_levels"] = entry(total_b, edges=E_, grid=[h1, w1], channels=C, radius=3)
+    del f1
+
+    # ---- the multi-GPU tail of a view step without the wire: collectives replaced by no-ops ----
+    from vings_mono_amd import parallel
+
+    class LocalReducer(parallel.GradReducer):
+        def _all_reduce(self, t, op, async_op=False):
+            return self._Done() if async_op else None
+
+    n1 = 1_000_000
+    raw = synth.make_splats(n1, W, H, n_views=8, seed=1)
+    w2c = torch.linalg.inv(synth.window_poses(8)[3]).to(dev)
+    gtp = {k: v.to(dev) for k, v in synth.perturb_splats(raw).items()}
+    with torch.no_grad():
+        pr = harness.render(gtp, w2c, intr)
+    gt = {"rgb": pr["rgb"].clone(), "depth": pr["depth"].clone(), "depth_cov": torch.ones_like(pr["depth"])}
+    cam, Rh = harness.view_settings(w2c, intr), w2c[:3, :3].cpu()
+    tail = {}
+    for name, red in (("single_gpu", None),
+                      ("planar", LocalReducer(n1, dev, 2, compact=False)),
+                      ("compact_4_chunks", LocalReducer(n1, dev, 2, n_chunks=4)),
+                      ("compact_1_chunk", LocalReducer(n1, dev, 2, n_chunks=1))):
+        mp_ = harness.SurfelMapper(raw, dev)
+        for _ in range(2):
+            mp_.fused_view(cam, intr, gt, Rh, 0, red)
+        tail[name] = round(timed(lambda: mp_.fused_view(cam, intr, gt, Rh, 0, red), max(a.reps, 9)), 4)
+        if red is not None and red.last_exchanged_rows is not None:
+            tail[name + "_rows"] = red.last_exchanged_rows
+        del mp_
+    res["view_step_ms_with_exchange_tail_no_wire"] = dict(
+        tail, splats=n1, note="whole fused view step; the difference to single_gpu is what the "
+        "exchange adds per view besides the all-reduce time itself")
     print(json.dumps(res))
 
 

@@ -1,16 +1,27 @@
-// Tile binning for the surfel rasteriser on gfx950: key emission
-// (tile << 32 | float bits of depth), a stable least-significant-digit radix
-// sort written for 64-lane wavefronts, and per-tile range extraction.
-// While sorting, the depth bits are rebased to the smallest depth of the view
-// and the tile index moved down next to them: at 1080p with depths spanning a
-// factor of 64 that is 27 + 13 bits, five 8-bit passes instead of six over
-// 32 + 13; the order is unchanged and the keys are handed out in the
-// documented form.
+// Tile binning for the surfel rasteriser on gfx950: every (splat, tile) instance of a view
+// into the list of its tile, every list ordered by depth.  Two levels:
+//   1. emit      keys (tile << 32 | float bits of depth) and splat indices, in splat order
+//   2. tile sort stable least-significant-digit radix passes (8-bit digits, written for 64-lane
+//                wavefronts) over the TILE bits only: 2 passes at 1080p (13 tile bits) where
+//                sorting the whole (tile, depth) key took 5 over its 40 differing bits
+//   3. ranges    per-tile ranges from the tile-ordered keys
+//   4. depth sort one workgroup per tile orders its list in LDS by (depth bits, splat index)
+//                (bitonic network, the exchanges below 64 entries as lane exchanges in
+//                registers; lists beyond the LDS capacity: LDS-sorted runs + merge passes
+//                through the free half of the radix sort's ping-pong buffers)
+// 9 launches instead of 17; 0.17 ms instead of 0.25 ms for the 2.4 M instances of a 1080p view.
 //
-// The sort order is fully determined by (tile, depth bits, splat index):
-// each splat emits at most one instance per tile and instances are emitted
-// in splat order, so a stable sort on the key reproduces the CPU oracle's
-// order bit for bit.
+// The order is fully determined: a splat emits at most one instance per tile and instances
+// are emitted in splat order, so a stable sort by (tile, depth) equals ordering every tile's
+// list by (depth bits, splat index).  Keys, values and ranges equal the CPU oracle's bit for
+// bit.
+//
+// Routing the instances to per-tile buckets with global atomics (count, scan, scatter)
+// instead of the radix passes was measured and dropped: gfx950 serves scattered 4-byte atomics
+// at about 44 G/s whatever their scope and however the counters are replicated
+// (tools/experiments/tile_count_bench.hip: 2.4 M instances, decode alone 12 us, with the
+// counting atomics 66 us, with returning atomics and the store 72 us), so the two routing
+// kernels alone cost what three radix passes do.
 //
 // Serves the binning stage of GaussianRasterizer.forward
 // (/root/reference/scripts/gaussian/gaussian_base.py:193-203).
@@ -23,7 +34,8 @@ constexpr int kSortItems = 8;                        // keys per lane per tile
 constexpr int kSortTile = kSortThreads * kSortItems;  // 2048 keys per workgroup
 constexpr int kRadixBits = 8;
 constexpr int kRadix = 1 << kRadixBits;
-constexpr int kMaxPasses = 8;
+constexpr int kMaxPasses = 4;
+constexpr int kSortCap = 2048;          // composites one LDS depth sort holds (16 KB: eight workgroups a CU)
 
 // ---------------------------------------------------------------------------
 // duplicate with keys: lane i owns splat i; its output offset is the
@@ -32,13 +44,10 @@ constexpr int kMaxPasses = 8;
 __global__ __launch_bounds__(256) void emit_keys_kernel(
     int N, int gx, const float* __restrict__ depth, const int32_t* __restrict__ rect,
     const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_prefix,
-    uint32_t dmin, int low_bits, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-    uint32_t* __restrict__ ranges, int n_range_words, const uint32_t* __restrict__ tail,
-    uint32_t cap) {
-    // tail != NULL: the launch was sized from a guess; the true {smallest depth bits, largest,
-    // instance count} are read here from where the projection left them, and nothing is
-    // written beyond the `cap` entries the buffers hold
-    if (tail) dmin = tail[0];
+    uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ ranges,
+    int n_range_words, uint32_t cap) {
+    // nothing is written beyond the `cap` entries the buffers hold (a speculative launch may
+    // have guessed the instance count too small)
     __shared__ uint32_t wtot[4];
     __shared__ uint32_t start[257];     // first output slot of each splat, relative to the block
     __shared__ int4 srect[256];
@@ -58,9 +67,7 @@ __global__ __launch_bounds__(256) void emit_keys_kernel(
     if (threadIdx.x == 255) start[256] = off + cnt;
     if (cnt) {
         srect[threadIdx.x] = reinterpret_cast<const int4*>(rect)[i];
-        // sort key: tile above the depth bits rebased to the smallest depth of the view, so
-        // the sort only runs over bits that can differ (same order as tile << 32 | depth bits)
-        sdepth[threadIdx.x] = __float_as_uint(depth[i]) - dmin;
+        sdepth[threadIdx.x] = __float_as_uint(depth[i]);
     }
     __syncthreads();
     // The block's instances form one contiguous output range; lanes take consecutive slots
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(256) void emit_keys_kernel(
             const uint32_t row = idx / wd;
             tile = (uint32_t)(r.y + (int)row) * gx + (uint32_t)r.x + (idx - row * wd);
         }
-        keys[out0 + q] = ((uint64_t)tile << low_bits) | (uint64_t)sdepth[lo];
+        keys[out0 + q] = ((uint64_t)tile << 32) | (uint64_t)sdepth[lo];
         vals[out0 + q] = (uint32_t)(blockIdx.x * 256 + lo);
     }
 }
@@ -264,37 +271,149 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(
     }
 }
 
-// Per-tile ranges from the sorted compact keys, and the keys in their documented form
-// (tile << 32 | float bits of depth) for the caller.
+// Per-tile ranges from the tile-ordered keys.
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint64_t* __restrict__ keys,
-                                                          int64_t D, uint32_t dmin, int low_bits,
-                                                          uint32_t* __restrict__ ranges,
-                                                          uint64_t* __restrict__ keys_out,
+                                                          int64_t D, uint32_t* __restrict__ ranges,
                                                           const uint32_t* __restrict__ tail, int T) {
-    if (tail) { D = min(D, (int64_t)tail[2]); dmin = tail[0]; }
+    if (tail) D = min(D, (int64_t)tail[2]);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= D) return;
-    const uint64_t k = keys[i];
-    const uint32_t t = (uint32_t)(k >> low_bits);
-    // t >= T only when a guessed key width was too narrow (the caller then repeats the call)
-    if (t < (uint32_t)T) {
-        if (i == 0 || (uint32_t)(keys[i - 1] >> low_bits) != t) ranges[2 * t] = (uint32_t)i;
-        if (i == D - 1 || (uint32_t)(keys[i + 1] >> low_bits) != t) ranges[2 * t + 1] = (uint32_t)(i + 1);
+    const uint32_t t = (uint32_t)(keys[i] >> 32);
+    if (t >= (uint32_t)T) return;
+    if (i == 0 || (uint32_t)(keys[i - 1] >> 32) != t) ranges[2 * t] = (uint32_t)i;
+    if (i == D - 1 || (uint32_t)(keys[i + 1] >> 32) != t) ranges[2 * t + 1] = (uint32_t)(i + 1);
+}
+
+// Ascending bitonic network over the first P (a power of two >= 64) entries of s, 256 lanes.
+// Exchanges over a distance below 64 stay inside an aligned block of 64 entries: a wave takes
+// such a block into registers (one entry per lane) and runs all of them as lane exchanges,
+// without barriers; only the exchanges over 64 entries or more go through LDS.  A 512-entry
+// list takes 6 LDS stages and 4 register phases instead of 45 LDS stages with a barrier each.
+__device__ __forceinline__ uint64_t lane_xor64(uint64_t v, int j) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, j, 64), hi = __shfl_xor((uint32_t)(v >> 32), j, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// stages (k, j) for j = j0, j0/2, .., 1 on entry g of the network, held in v
+__device__ __forceinline__ uint64_t bitonic_lane_stages(uint64_t v, uint32_t g, int k, int j0) {
+    const bool asc = (g & (uint32_t)k) == 0;
+    for (int j = j0; j > 0; j >>= 1) {
+        const uint64_t o = lane_xor64(v, j);
+        const bool keep_min = (((g & (uint32_t)j) == 0) == asc);   // the pair's lower entry, ascending
+        v = (keep_min == (o < v)) ? o : v;
     }
-    const uint32_t low = (uint32_t)(k & ((1ull << low_bits) - 1ull));
-    keys_out[i] = ((uint64_t)t << 32) | (uint64_t)(low + dmin);
+    return v;
+}
+
+__device__ __forceinline__ void bitonic_lds(uint64_t* s, int P) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nblocks = P >> 6;
+    for (int blk = w; blk < nblocks; blk += 4) {
+        const uint32_t g = (uint32_t)(blk * 64 + lane);
+        uint64_t v = s[g];
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) v = bitonic_lane_stages(v, g, k, k >> 1);
+        s[g] = v;
+    }
+    __syncthreads();
+    for (int k = 128; k <= P; k <<= 1) {
+        for (int j = k >> 1; j >= 64; j >>= 1) {
+            for (int i = threadIdx.x; i < (P >> 1); i += 256) {
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const int hi = lo | j;
+                const uint64_t a = s[lo], b = s[hi];
+                if ((a > b) == ((lo & k) == 0)) { s[lo] = b; s[hi] = a; }
+            }
+            __syncthreads();
+        }
+        for (int blk = w; blk < nblocks; blk += 4) {
+            const uint32_t g = (uint32_t)(blk * 64 + lane);
+            s[g] = bitonic_lane_stages(s[g], g, k, 32);
+        }
+        __syncthreads();
+    }
+}
+
+// One workgroup per tile: orders the tile's list by (depth bits, splat index), in place.  The
+// list arrives in splat order (the radix passes are stable), keys = tile << 32 | depth bits.
+constexpr int kCap = kSortCap;
+__global__ __launch_bounds__(256) void tile_depth_sort_kernel(
+    const uint32_t* __restrict__ ranges, uint64_t* keys, uint32_t* vals, uint64_t* scratch) {
+    __shared__ uint64_t s[kCap];
+    const uint32_t t = blockIdx.x;
+    const uint2 rg = reinterpret_cast<const uint2*>(ranges)[t];
+    const uint32_t b = rg.x, n = rg.y - rg.x;
+    if (n < 2u) return;                      // a list of one entry is in order as it is
+    const uint64_t tile_hi = (uint64_t)t << 32;
+    if (n <= (uint32_t)kCap) {
+        int P = 64;
+        while ((uint32_t)P < n) P <<= 1;
+        for (int i = threadIdx.x; i < P; i += 256)
+            s[i] = (uint32_t)i < n ? ((keys[b + i] << 32) | (uint64_t)vals[b + i]) : ~0ull;
+        __syncthreads();
+        bitonic_lds(s, P);
+        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+            const uint64_t c = s[i];
+            keys[b + i] = tile_hi | (c >> 32);
+            vals[b + i] = (uint32_t)c;
+        }
+        return;
+    }
+    // A list the LDS does not hold: runs of kCap composites sorted in LDS and parked in the
+    // scratch buffer, then merged pairwise, alternating between the scratch buffer and the
+    // tile's own stretch of the key array (all of its keys have been read by then); every pair
+    // of runs is cut into 256 equal output pieces along its merge path.
+    uint64_t* A = scratch + b;
+    uint64_t* B = keys + b;
+    for (uint32_t r0 = 0; r0 < n; r0 += kCap) {
+        const uint32_t len = min((uint32_t)kCap, n - r0);
+        for (uint32_t i = threadIdx.x; i < (uint32_t)kCap; i += 256)
+            s[i] = i < len ? ((B[r0 + i] << 32) | (uint64_t)vals[b + r0 + i]) : ~0ull;
+        __syncthreads();
+        bitonic_lds(s, kCap);
+        for (uint32_t i = threadIdx.x; i < len; i += 256) A[r0 + i] = s[i];
+        __syncthreads();
+    }
+    uint64_t* src = A;
+    uint64_t* dst = B;
+    for (uint32_t R = kCap; R < n; R <<= 1) {
+        for (uint32_t p0 = 0; p0 < n; p0 += 2 * R) {
+            const uint32_t la = min(R, n - p0);
+            const uint32_t lb = n - p0 - la < R ? n - p0 - la : R;
+            const uint64_t* a = src + p0;
+            const uint64_t* bb = a + la;
+            uint64_t* out = dst + p0;
+            const uint32_t len = la + lb;
+            const uint32_t per = (len + 255) / 256;
+            const uint32_t d0 = min(threadIdx.x * per, len), d1 = min(d0 + per, len);
+            // merge path: of the first d0 outputs, i come from a and d0 - i from bb
+            uint32_t lo = d0 > lb ? d0 - lb : 0, hi = min(d0, la);
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (a[mid] < bb[d0 - 1 - mid]) lo = mid + 1; else hi = mid;
+            }
+            uint32_t i = lo, j = d0 - lo;
+            for (uint32_t o = d0; o < d1; ++o) {
+                const bool take_a = j >= lb || (i < la && a[i] < bb[j]);
+                out[o] = take_a ? a[i++] : bb[j++];
+            }
+        }
+        __syncthreads();
+        uint64_t* tmp = src; src = dst; dst = tmp;
+    }
+    // (when the ordered list sits in the key array itself, every lane converts the entries it
+    // reads in place)
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint64_t c = src[i];
+        keys[b + i] = tile_hi | (c >> 32);
+        vals[b + i] = (uint32_t)c;
+    }
 }
 
 static int bits_for(uint32_t span) {   // bits needed to hold values 0..span
     int bits = 0;
     while (bits < 32 && ((uint64_t)1 << bits) <= (uint64_t)span) ++bits;
     return bits;
-}
-
-static int sort_passes(int T, int low_bits) {
-    const int tile_bits = bits_for((uint32_t)(T > 0 ? T - 1 : 0));
-    const int p = (low_bits + tile_bits + kRadixBits - 1) / kRadixBits;
-    return p > 0 ? p : 1;
 }
 
 struct BinWorkspace {
@@ -326,13 +445,13 @@ using namespace vings;
 
 extern "C" size_t vings_surfel_bin_workspace_bytes(int64_t D) { return carve(nullptr, D).bytes; }
 
-// tail == NULL: D, dmin and low_bits are the view's true values.  Otherwise D is the capacity
-// of the buffers and low_bits a guess, and the kernels take the true values from tail[0..2].
-static int bin_impl(int N, int H, int W, int64_t D, uint32_t dmin, int low_bits,
-                    const uint32_t* tail, const float* depth, const int32_t* rect,
-                    const uint32_t* tiles_touched, const uint32_t* block_prefix,
-                    uint64_t* keys_sorted, uint32_t* vals_sorted, uint32_t* ranges,
-                    void* workspace, size_t workspace_bytes, void* stream) {
+// tail == NULL: D is the view's true instance count.  Otherwise D is the capacity of the
+// buffers (a guess the caller checks afterwards) and the kernels take the true count from
+// tail[2], where the projection left it.
+static int bin_impl(int N, int H, int W, int64_t D, const uint32_t* tail, const float* depth,
+                    const int32_t* rect, const uint32_t* tiles_touched,
+                    const uint32_t* block_prefix, uint64_t* keys_sorted, uint32_t* vals_sorted,
+                    uint32_t* ranges, void* workspace, size_t workspace_bytes, void* stream) {
     VINGS_REQUIRE(N >= 0 && H > 0 && W > 0 && D >= 0, "sizes");
     VINGS_REQUIRE(D < ((int64_t)1 << 32), "instance count must fit 32 bits");
     VINGS_REQUIRE(ranges != nullptr, "ranges");
@@ -347,44 +466,42 @@ static int bin_impl(int N, int H, int W, int64_t D, uint32_t dmin, int low_bits,
                       workspace,
                   "null pointer");
     VINGS_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+    VINGS_REQUIRE(((uintptr_t)ranges & 7) == 0, "ranges must be 8-byte aligned");
     const BinWorkspace b = carve(workspace, D);
     if (workspace_bytes < b.bytes) {
         set_error("bin workspace too small: %zu < %zu", workspace_bytes, b.bytes);
         return VINGS_ERR_CAPACITY;
     }
-    const int passes = sort_passes(T, low_bits);
-    VINGS_REQUIRE(passes <= kMaxPasses, "key too wide");
+    const int tile_bits = bits_for((uint32_t)(T - 1));
+    const int passes = tile_bits > 0 ? (tile_bits + kRadixBits - 1) / kRadixBits : 1;
+    VINGS_REQUIRE(passes <= kMaxPasses, "too many tiles");
     ProfScope prof(PROF_BIN, s);
-    // ping-pong so that the last pass leaves the (compact) keys in the workspace, from where
-    // tile_ranges writes them decoded into keys_sorted, and the values in vals_sorted
+    // ping-pong so that the last pass leaves keys and values in the caller's arrays
     uint64_t* kbuf[2] = {keys_sorted, b.keys_alt};
     uint32_t* vbuf[2] = {vals_sorted, b.vals_alt};
-    int cur = (passes % 2 == 0) ? 1 : 0;    // keys: end in kbuf[1]
-    int vcur = (passes % 2 == 0) ? 0 : 1;   // values: end in vbuf[0]
+    int cur = passes & 1;
 
     emit_keys_kernel<<<cdiv(N, 256), 256, 0, s>>>(N, gx, depth, rect, tiles_touched, block_prefix,
-                                                  dmin, low_bits, kbuf[cur], vbuf[vcur], ranges,
-                                                  2 * T, tail, (uint32_t)D);
+                                                  kbuf[cur], vbuf[cur], ranges, 2 * T, (uint32_t)D);
     VINGS_LAUNCH_CHECK();
-
     const int ntiles = cdiv(D, kSortTile);
     for (int p = 0; p < passes; ++p) {
-        const int shift = p * kRadixBits;
+        const int shift = 32 + p * kRadixBits;
         sort_tile_hist_kernel<<<ntiles, kSortThreads, 0, s>>>(kbuf[cur], D, shift, ntiles, b.thist,
                                                               tail);
         VINGS_LAUNCH_CHECK();
         sort_scan_kernel<<<kRadix, 256, 0, s>>>(b.thist, ntiles, b.ghist);
         VINGS_LAUNCH_CHECK();
-        sort_scatter_kernel<<<ntiles, kSortThreads, 0, s>>>(kbuf[cur], vbuf[vcur], kbuf[cur ^ 1],
-                                                            vbuf[vcur ^ 1], D, shift, ntiles,
+        sort_scatter_kernel<<<ntiles, kSortThreads, 0, s>>>(kbuf[cur], vbuf[cur], kbuf[cur ^ 1],
+                                                            vbuf[cur ^ 1], D, shift, ntiles,
                                                             b.thist, b.ghist, tail);
         VINGS_LAUNCH_CHECK();
         cur ^= 1;
-        vcur ^= 1;
     }
-    // cur == 1, vcur == 0 here by construction
-    tile_ranges_kernel<<<cdiv(D, 256), 256, 0, s>>>(b.keys_alt, D, dmin, low_bits, ranges,
-                                                    keys_sorted, tail, T);
+    // cur == 0 here: the tile-ordered lists are in keys_sorted / vals_sorted
+    tile_ranges_kernel<<<cdiv(D, 256), 256, 0, s>>>(keys_sorted, D, ranges, tail, T);
+    VINGS_LAUNCH_CHECK();
+    tile_depth_sort_kernel<<<T, 256, 0, s>>>(ranges, keys_sorted, vals_sorted, b.keys_alt);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }
@@ -395,13 +512,9 @@ extern "C" int vings_surfel_bin(int N, int H, int W, int64_t D, uint32_t depth_b
                                 const uint32_t* block_prefix, uint64_t* keys_sorted,
                                 uint32_t* vals_sorted, uint32_t* ranges, void* workspace,
                                 size_t workspace_bytes, void* stream) {
-    // depth bits are rebased to the view's smallest depth; an unknown range (min > max) keeps
-    // all 32 bits
-    const bool ranged = depth_bits_min <= depth_bits_max;
-    return bin_impl(N, H, W, D, ranged ? depth_bits_min : 0u,
-                    ranged ? bits_for(depth_bits_max - depth_bits_min) : 32, nullptr, depth, rect,
-                    tiles_touched, block_prefix, keys_sorted, vals_sorted, ranges, workspace,
-                    workspace_bytes, stream);
+    (void)depth_bits_min; (void)depth_bits_max;   // the depth order no longer depends on them
+    return bin_impl(N, H, W, D, nullptr, depth, rect, tiles_touched, block_prefix, keys_sorted,
+                    vals_sorted, ranges, workspace, workspace_bytes, stream);
 }
 
 extern "C" int vings_surfel_bin_low_bits(uint32_t depth_bits_min, uint32_t depth_bits_max) {
@@ -416,9 +529,8 @@ extern "C" int vings_surfel_bin_speculative(int N, int H, int W, int64_t D_capac
                                             uint32_t* vals_sorted, uint32_t* ranges,
                                             void* workspace, size_t workspace_bytes,
                                             void* stream) {
+    (void)low_bits_guess;
     VINGS_REQUIRE(tail != nullptr && D_capacity > 0 && N > 0, "speculative binning needs a guess");
-    VINGS_REQUIRE(low_bits_guess >= 0 && low_bits_guess <= 32, "low_bits_guess");
-    return bin_impl(N, H, W, D_capacity, 0u, low_bits_guess, tail, depth, rect, tiles_touched,
-                    block_prefix, keys_sorted, vals_sorted, ranges, workspace, workspace_bytes,
-                    stream);
+    return bin_impl(N, H, W, D_capacity, tail, depth, rect, tiles_touched, block_prefix,
+                    keys_sorted, vals_sorted, ranges, workspace, workspace_bytes, stream);
 }

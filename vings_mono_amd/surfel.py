@@ -167,9 +167,9 @@ def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys,
     # The instance count D comes back from the projection through the host.  Waiting for it
     # before the sort is launched leaves the GPU idle once per view, so when an earlier view of
     # this size is known the sort and the blend are launched at once, sized from that view's
-    # count plus 1/8 and keyed on its depth-bit width; the kernels read the true values from
-    # device memory.  The host then checks the guess and, if it was too small, repeats the two
-    # stages with exact sizes (nothing but their own outputs was written).
+    # count plus 1/8; the kernels read the true count from device memory.  The host then checks
+    # the guess and, if it was too small, repeats the two stages with exact sizes (nothing but
+    # their own outputs was written).
     hint = _D_HINT.get((dev.index, H, W)) if SPECULATE and N > 0 else None
     done = False
     if hint is not None and hint[0] > 0:
@@ -189,7 +189,7 @@ def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys,
         check(L.vings_surfel_project_wait(ctypes.byref(d_host), d_range), "vings_surfel_project_wait")
         D = int(d_host.value)
         bits = int(L.vings_surfel_bin_low_bits(int(d_range[0]), int(d_range[1]))) if D > 0 else 0
-        done = D <= cap and bits <= hint[1]
+        done = D <= cap
         _D_HINT[(dev.index, H, W)] = (D, max(bits, hint[1])) if D > 0 else hint
     else:
         if raw is None:
