@@ -97,6 +97,10 @@ int vings_surfel_project(int N, int H, int W, float scale_modifier,
  *    list, and rect holds for such a splat {1<<31 | x0 | y0<<15, width, tile bits lo, hi}
  *    (one bit per tile of the rectangle, row-major) instead of {x0, y0, x1, y1}. */
 int vings_surfel_set_tight_binning(int on);
+/* The same choice for the projections launched by the CALLING THREAD only (1 / 0; -1: follow
+ * the process-wide switch again, the initial state); returns the thread's previous value.
+ * Threads that render on one GPU with different binning modes do not disturb each other. */
+int vings_surfel_set_tight_binning_thread(int mode);
 
 /* The same call in two halves, for callers that do not want the GPU to idle while the host
  * learns D: launch returns at once; wait blocks until the projection launched last on the

@@ -430,19 +430,26 @@ def test_two_threads_render_on_one_gpu():
     """Two host threads, each on its own stream, render different scenes on the same GPU at
     the same time (main map and sky model, /root/reference/scripts/gaussian/sky_utils.py:135-162):
     every launch has its own mailbox slot, so each thread reads its own instance count and
-    gets the bits a solitary render gives."""
+    gets the bits a solitary render gives.  The two threads also use different binning modes
+    (thread 0 the reference's squares, thread 1 the tight footprint), each its own."""
     import threading
+    from vings_mono_amd import surfel
     dev = torch.device("cuda:0")
     jobs = [(synth.make_splats(6000, 320, 192, n_views=2, seed=61), 320, 192),
             (synth.make_splats(15000, 256, 160, n_views=2, seed=62), 256, 160)]
-    want = [_forward_state(raw, W, H) for raw, W, H in jobs]
+    want = []
+    for k, (raw, W, H) in enumerate(jobs):
+        with surfel.thread_binning(tight=(k == 1)):
+            want.append(_forward_state(raw, W, H))
+    with surfel.thread_binning(tight=True):
+        assert _forward_state(*jobs[0]).D < want[0].D        # the modes do differ on this scene
     torch.cuda.synchronize()
     errors = []
 
     def work(k):
         try:
             raw, W, H = jobs[k]
-            with torch.cuda.stream(torch.cuda.Stream(dev)):
+            with surfel.thread_binning(tight=(k == 1)), torch.cuda.stream(torch.cuda.Stream(dev)):
                 for _ in range(25):
                     got = _forward_state(raw, W, H)
                     torch.cuda.current_stream().synchronize()

@@ -23,6 +23,7 @@ _SIGNATURES = {
     "vings_surfel_project_launch": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float] + [_P] * 15),
     "vings_surfel_project_launch_activate": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float] + [_P] * 19),
     "vings_surfel_set_tight_binning": (_c.c_int, [_c.c_int]),
+    "vings_surfel_set_tight_binning_thread": (_c.c_int, [_c.c_int]),
     "vings_surfel_project_wait": (_c.c_int, [_c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
     "vings_surfel_bin_low_bits": (_c.c_int, [_c.c_uint32, _c.c_uint32]),
     "vings_surfel_bin_speculative": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_int] +

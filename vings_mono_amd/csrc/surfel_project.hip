@@ -517,7 +517,8 @@ std::atomic<unsigned> g_mail_next[kMaxDevices];
 thread_local int t_mail_dev = -1, t_mail_slot = -1;      // the calling thread's latest launch
 // 1: a splat is binned only into the tiles its alpha >= 1/255 box reaches (the default);
 // 0: into every tile of the reference's 3-sigma square (forward.cu preprocess / getRect).
-std::atomic<int> g_tight_binning{1};
+std::atomic<int> g_tight_binning{1};   // process default
+thread_local int t_tight_binning = -1;  // the calling thread's choice; -1: the process default
 }  // namespace
 
 }  // namespace vings
@@ -555,7 +556,8 @@ static int project_launch(int N, int H, int W, float scale_modifier, const float
     }
     const int slot = (int)(g_mail_next[dev].fetch_add(1u, std::memory_order_relaxed) % kMailSlots);
     const int nb = cdiv(N, 256);
-    const int tight = g_tight_binning.load(std::memory_order_relaxed);
+    const int tight = t_tight_binning >= 0 ? t_tight_binning
+                                           : g_tight_binning.load(std::memory_order_relaxed);
     {
     ProfScope prof(PROF_PROJECT_FWD, s);
     if (act_scales)
@@ -652,6 +654,12 @@ extern "C" int vings_surfel_project_launch_activate(
 
 extern "C" int vings_surfel_set_tight_binning(int on) {
     return g_tight_binning.exchange(on ? 1 : 0);
+}
+
+extern "C" int vings_surfel_set_tight_binning_thread(int mode) {
+    const int prev = t_tight_binning;
+    t_tight_binning = mode < 0 ? -1 : (mode ? 1 : 0);
+    return prev;
 }
 
 extern "C" int vings_surfel_project_wait(int64_t* num_instances_host,

@@ -64,6 +64,23 @@ def set_tight_binning(on):
     return bool(_lib.lib().vings_surfel_set_tight_binning(1 if on else 0))
 
 
+class thread_binning:
+    """`with thread_binning(tight=False): ...` — the binning mode of the projections the
+    calling thread launches inside the block, whatever the process-wide switch says and
+    without touching it (other threads rendering on the same GPU keep their own mode)."""
+
+    def __init__(self, tight):
+        self.mode = 1 if tight else 0
+
+    def __enter__(self):
+        self.prev = _lib.lib().vings_surfel_set_tight_binning_thread(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.lib().vings_surfel_set_tight_binning_thread(self.prev)
+        return False
+
+
 def rasterize_forward(means3D, colors, opacities, scales, rotations, settings, keep_keys=False,
                       raw=None, dgeom=None):
     """Run projection -> binning -> blend. Returns (SurfelForwardState, aux).
