@@ -59,6 +59,9 @@ def parse():
                     help="N > 1: compact = only the rows some rank touched travel, in chunks "
                          "applied while the next one is reduced; planar = all rows in one all-reduce")
     ap.add_argument("--exchange-chunks", type=int, default=4)
+    ap.add_argument("--no-graph-run", action="store_true",
+                    help="skip the graph_replay side figure (N = 1: the same step with every view "
+                         "replayed from a HIP graph captured per keyframe)")
     ap.add_argument("--autograd", action="store_true",
                     help="drive the view step through torch autograd and PyTorch bookkeeping "
                          "instead of the fused C-ABI sequence")
@@ -210,9 +213,11 @@ def main():
     R_host = [w[:3, :3].cpu() for w in w2c_dev]
     cams = [harness.view_settings(w, intr) for w in w2c_dev]
 
-    def step(autograd=args.autograd, torch_loss=args.torch_loss):
+    def step(autograd=args.autograd, torch_loss=args.torch_loss, graphed=False):
         for i, k in enumerate(my_views):
-            if autograd or torch_loss:
+            if graphed:
+                mapper.fused_view_graphed(k, cams[i], intr, gts[i], R_host[i], k)
+            elif autograd or torch_loss:
                 # the reference's formulation: PyTorch activations / autograd / bookkeeping
                 # around the rasteriser (and, with --torch-loss, the PyTorch loss graph)
                 radii, cur = mapper.backward_view(w2c_dev[i], intr, gts[i], Rw2c_host=R_host[i],
@@ -275,7 +280,12 @@ def main():
         barrier()
         return round(n_views_total * n_steps / (time.perf_counter() - t), 3)
 
-    reference_api = reference_binning = None
+    reference_api = reference_binning = graph_replay = None
+    if world == 1 and not args.no_side_runs and not args.no_graph_run and loop is None \
+            and not (args.autograd or args.torch_loss):
+        step(graphed=True)          # eager: learns the instance counts
+        step(graphed=True)          # captures one graph per keyframe
+        graph_replay = side_run(n_steps=args.steps, graphed=True)
     if world == 1 and not args.no_side_runs and not (args.autograd or args.torch_loss) and loop is None:
         # the reference's own call pattern (gaussian_base.py:367-403): PyTorch activations,
         # GaussianRasterizer through autograd, the PyTorch loss graph, loss.backward(), PyTorch
@@ -348,6 +358,12 @@ def main():
                 "value": reference_api, "unit": "frames/s",
                 "what": "same step through GaussianRasterizer autograd + PyTorch loss graph + "
                         "PyTorch bookkeeping (the reference's call pattern, gaussian_base.py:367-403)"},
+            "graph_replay": None if graph_replay is None else {
+                "value": graph_replay, "unit": "frames/s",
+                "what": "the same fused step with every view replayed from a HIP graph captured "
+                        "once per keyframe of the window (SurfelMapper.fused_view_graphed); per-kernel "
+                        "events cannot be recorded inside a replay, so the headline value and the "
+                        "roofline are taken on the eager launches"},
             "reference_binning": None if reference_binning is None else {
                 "value": reference_binning, "unit": "frames/s", "instances_D": reference_binning_D,
                 "what": "fused step with the reference's 3-sigma tile squares (bit-exact instance list)"},

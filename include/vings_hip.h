@@ -287,6 +287,44 @@ int vings_surfel_project_backward_finish(
     int64_t* record_keys, void* stream);
 
 /* ------------------------------------------------------------------------
+ * The view step under HIP stream capture (one graph per keyframe of the window, replayed every
+ * iteration).  A graph has fixed buffers, so the view is binned into a fixed capacity, and the
+ * host cannot look at the instance count in the middle of it.  Three entry points make that
+ * safe; none of them synchronises, records an event or touches the library's mailboxes:
+ *   vings_surfel_project_enqueue_activate   vings_surfel_project_launch_activate with the three
+ *       count words {depth bits min, max, instance count D} written to count_words, memory of
+ *       the caller that the GPU can write (pinned host memory: the host reads D from it
+ *       whenever it next looks; or device memory).  Follow it with
+ *       vings_surfel_bin_speculative(capacity, tail = block_prefix + 3*ceil(N/256) + 1).
+ *   vings_surfel_project_backward_finish_guarded, vings_sparse_adam_multi_guarded   the
+ *       single-GPU finish (bookkeeping on) and the Adam step, which do NOTHING when
+ *       *instance_count > capacity: a view whose instance list did not fit was blended from a
+ *       truncated list, so its step is dropped as a whole and the map stays as it was; the
+ *       caller sees D > capacity in count_words afterwards and repeats the step with room.
+ * No counterpart in the reference (its view step is eager PyTorch, gaussian_base.py:353-404). */
+int vings_surfel_project_enqueue_activate(
+    int N, int H, int W, float scale_modifier, const float* means3D, const float* raw_scaling,
+    const float* raw_rotation, const float* raw_opacity, const float* colors, const float* flow,
+    const float* viewmatrix, const float* projmatrix, float* scales, float* rotations,
+    float* opacities, float* geom, float* depth, int32_t* radii, int32_t* rect,
+    uint32_t* tiles_touched, uint32_t* block_prefix, float* dgeom_clear, uint32_t* count_words,
+    void* stream);
+int vings_surfel_project_backward_finish_guarded(
+    int N, int H, int W, float scale_modifier, const float* means3D, const float* scales,
+    const float* rotations, const float* viewmatrix, const float* projmatrix, const int32_t* radii,
+    const float* dgeom, const float* opacities, const float* raw_rotation,
+    const uint8_t* stable_mask, float* global_scores, float* local_scores, float* kf_max_scores,
+    int64_t* kf_id, int64_t this_kf, float* g_xyz, float* g_rgb, float* g_opacity,
+    float* g_scaling, float* g_rotation, uint8_t* visible, const uint32_t* instance_count,
+    uint32_t capacity, void* stream);
+int vings_sparse_adam_multi_guarded(int n_groups, float* const* params_host,
+                                    const float* const* grads_host, float* const* exp_avgs_host,
+                                    float* const* exp_avg_sqs_host, const int* widths_host,
+                                    const float* lrs_host, const uint8_t* visible, float b1,
+                                    float b2, float eps, int N, const uint32_t* instance_count,
+                                    uint32_t capacity, void* stream);
+
+/* ------------------------------------------------------------------------
  * Compact exchange of one view step between the GPUs of a sharded mapping job (one process
  * per GPU, every GPU holds the whole splat set and renders its own keyframe; the reference is
  * single-GPU, configs/hierarchical/smallcity.yaml:11-13, so these have no counterpart there).

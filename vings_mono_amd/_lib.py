@@ -22,6 +22,11 @@ _SIGNATURES = {
                              [_c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32), _P]),
     "vings_surfel_project_launch": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float] + [_P] * 15),
     "vings_surfel_project_launch_activate": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float] + [_P] * 19),
+    "vings_surfel_project_enqueue_activate": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float] + [_P] * 20),
+    "vings_surfel_project_backward_finish_guarded": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float] +
+                                                     [_P] * 14 + [_c.c_int64] + [_P] * 7 + [_c.c_uint32, _P]),
+    "vings_sparse_adam_multi_guarded": (_c.c_int, [_c.c_int] + [_P] * 7 + [_c.c_float] * 3 +
+                                        [_c.c_int, _P, _c.c_uint32, _P]),
     "vings_surfel_set_tight_binning": (_c.c_int, [_c.c_int]),
     "vings_surfel_set_tight_binning_thread": (_c.c_int, [_c.c_int]),
     "vings_surfel_project_wait": (_c.c_int, [_c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),

@@ -53,7 +53,11 @@ __device__ __forceinline__ int64_t row_of(int64_t e, int M) {
 __global__ __launch_bounds__(256) void sparse_adam_multi_kernel(AdamGroups G,
                                                                 const uint8_t* __restrict__ visible,
                                                                 float b1, float b2, float eps,
-                                                                int N) {
+                                                                int N,
+                                                                const uint32_t* __restrict__ guard_count,
+                                                                uint32_t guard_limit) {
+    // (see vings_sparse_adam_multi_guarded: a step whose gradients are incomplete is skipped)
+    if (guard_count && *guard_count > guard_limit) return;
     int g = 0;
     while (g + 1 < G.n && (int)blockIdx.x >= G.first_block[g + 1]) ++g;
     const int M = G.width[g];
@@ -111,12 +115,11 @@ extern "C" int vings_sparse_adam(float* param, const float* grad, float* exp_avg
     return VINGS_OK;
 }
 
-extern "C" int vings_sparse_adam_multi(int n_groups, float* const* params_host,
-                                       const float* const* grads_host,
-                                       float* const* exp_avgs_host,
-                                       float* const* exp_avg_sqs_host, const int* widths_host,
-                                       const float* lrs_host, const uint8_t* visible, float b1,
-                                       float b2, float eps, int N, void* stream) {
+static int adam_multi(int n_groups, float* const* params_host, const float* const* grads_host,
+                      float* const* exp_avgs_host, float* const* exp_avg_sqs_host,
+                      const int* widths_host, const float* lrs_host, const uint8_t* visible,
+                      float b1, float b2, float eps, int N, void* stream,
+                      const uint32_t* guard_count, uint32_t guard_limit) {
     VINGS_REQUIRE(n_groups > 0 && n_groups <= kMaxGroups, "1..8 groups");
     VINGS_REQUIRE(N >= 0, "sizes");
     if (N == 0) return VINGS_OK;
@@ -145,7 +148,32 @@ extern "C" int vings_sparse_adam_multi(int n_groups, float* const* params_host,
     }
     G.first_block[n_groups] = blocks;
     ProfScope prof(PROF_ADAM, (hipStream_t)stream);
-    sparse_adam_multi_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(G, visible, b1, b2, eps, N);
+    sparse_adam_multi_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(G, visible, b1, b2, eps, N,
+                                                                      guard_count, guard_limit);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
+}
+
+extern "C" int vings_sparse_adam_multi(int n_groups, float* const* params_host,
+                                       const float* const* grads_host,
+                                       float* const* exp_avgs_host,
+                                       float* const* exp_avg_sqs_host, const int* widths_host,
+                                       const float* lrs_host, const uint8_t* visible, float b1,
+                                       float b2, float eps, int N, void* stream) {
+    return adam_multi(n_groups, params_host, grads_host, exp_avgs_host, exp_avg_sqs_host,
+                      widths_host, lrs_host, visible, b1, b2, eps, N, stream, nullptr, 0u);
+}
+
+extern "C" int vings_sparse_adam_multi_guarded(int n_groups, float* const* params_host,
+                                               const float* const* grads_host,
+                                               float* const* exp_avgs_host,
+                                               float* const* exp_avg_sqs_host,
+                                               const int* widths_host, const float* lrs_host,
+                                               const uint8_t* visible, float b1, float b2,
+                                               float eps, int N, const uint32_t* instance_count,
+                                               uint32_t capacity, void* stream) {
+    VINGS_REQUIRE(instance_count != nullptr, "instance_count");
+    return adam_multi(n_groups, params_host, grads_host, exp_avgs_host, exp_avg_sqs_host,
+                      widths_host, lrs_host, visible, b1, b2, eps, N, stream, instance_count,
+                      capacity);
 }

@@ -488,9 +488,12 @@ __global__ __launch_bounds__(256) void project_bwd_finish_kernel(
     int N, int H, int W, float scale_mod, const float* __restrict__ means3D,
     const float* __restrict__ rots, const float* __restrict__ view,
     const float* __restrict__ proj, const float* __restrict__ dgeom, FinishArgs a,
-    float* __restrict__ scores) {
+    float* __restrict__ scores, const uint32_t* __restrict__ guard_count, uint32_t guard_limit) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
+    // the view's instance list did not fit the buffers it was binned into: its gradients are
+    // incomplete, so nothing of this step may reach the records or the parameters
+    if (guard_count && *guard_count > guard_limit) return;
     SplatGrad g;
     splat_backward(i, H, W, scale_mod, means3D, a.scales, rots, view, proj, a.radii[i], dgeom, g);
     if (scores) reinterpret_cast<float2*>(scores)[i] = make_float2(g.sc[0], g.sc[1]);
@@ -534,7 +537,7 @@ static int project_launch(int N, int H, int W, float scale_modifier, const float
                           int32_t* rect, uint32_t* tiles_touched, uint32_t* block_prefix,
                           hipStream_t s, int* dev_out, float* act_scales = nullptr,
                           float* act_rotations = nullptr, float* act_opacities = nullptr,
-                          float* dgeom_clear = nullptr) {
+                          float* dgeom_clear = nullptr, uint32_t* user_tail = nullptr) {
     VINGS_REQUIRE(N > 0 && H > 0 && W > 0, "sizes");
     VINGS_REQUIRE(means3D && scales && rotations && opacities && colors && viewmatrix &&
                       projmatrix && geom && depth && radii && rect && tiles_touched && block_prefix,
@@ -544,7 +547,7 @@ static int project_launch(int N, int H, int W, float scale_modifier, const float
     int dev = 0;
     VINGS_CHECK_HIP(hipGetDevice(&dev));
     VINGS_REQUIRE(dev >= 0 && dev < kMaxDevices, "device index");
-    {
+    if (!user_tail) {
         std::lock_guard<std::mutex> lk(g_mail_mu[dev]);
         if (!g_mail[dev]) {
             uint32_t* m = nullptr;
@@ -554,7 +557,7 @@ static int project_launch(int N, int H, int W, float scale_modifier, const float
             g_mail[dev] = m;
         }
     }
-    const int slot = (int)(g_mail_next[dev].fetch_add(1u, std::memory_order_relaxed) % kMailSlots);
+    const int slot = user_tail ? -1 : (int)(g_mail_next[dev].fetch_add(1u, std::memory_order_relaxed) % kMailSlots);
     const int nb = cdiv(N, 256);
     const int tight = t_tight_binning >= 0 ? t_tight_binning
                                            : g_tight_binning.load(std::memory_order_relaxed);
@@ -571,6 +574,14 @@ static int project_launch(int N, int H, int W, float scale_modifier, const float
             nullptr, colors, flow, viewmatrix, projmatrix, geom, depth, radii, rect, tiles_touched,
             block_prefix, block_prefix + nb + 1, block_prefix + 2 * nb + 1, tight, nullptr);
     VINGS_LAUNCH_CHECK();
+    }
+    if (user_tail) {
+        // the caller's own count words, no mailbox slot, no event: nothing here that a stream
+        // capture could not record
+        scan_blocks_kernel<<<1, 1024, 0, s>>>(block_prefix, nb, user_tail);
+        VINGS_LAUNCH_CHECK();
+        *dev_out = dev;
+        return VINGS_OK;
     }
     scan_blocks_kernel<<<1, 1024, 0, s>>>(block_prefix, nb, g_mail[dev] + 16 * slot);
     VINGS_LAUNCH_CHECK();
@@ -652,6 +663,25 @@ extern "C" int vings_surfel_project_launch_activate(
                           opacities, dgeom_clear);
 }
 
+extern "C" int vings_surfel_project_enqueue_activate(
+    int N, int H, int W, float scale_modifier, const float* means3D, const float* raw_scaling,
+    const float* raw_rotation, const float* raw_opacity, const float* colors, const float* flow,
+    const float* viewmatrix, const float* projmatrix, float* scales, float* rotations,
+    float* opacities, float* geom, float* depth, int32_t* radii, int32_t* rect,
+    uint32_t* tiles_touched, uint32_t* block_prefix, float* dgeom_clear, uint32_t* count_words,
+    void* stream) {
+    VINGS_REQUIRE(scales && rotations && opacities && count_words, "null pointer");
+    VINGS_REQUIRE(((uintptr_t)dgeom_clear & 15) == 0, "dgeom must be 16-byte aligned");
+    VINGS_REQUIRE((((uintptr_t)rotations | (uintptr_t)raw_rotation) & 15) == 0 &&
+                      (((uintptr_t)scales | (uintptr_t)raw_scaling) & 7) == 0,
+                  "rotation arrays must be 16-byte aligned, scaling arrays 8-byte aligned");
+    int dev = 0;
+    return project_launch(N, H, W, scale_modifier, means3D, raw_scaling, raw_rotation, raw_opacity,
+                          colors, flow, viewmatrix, projmatrix, geom, depth, radii, rect,
+                          tiles_touched, block_prefix, (hipStream_t)stream, &dev, scales, rotations,
+                          opacities, dgeom_clear, count_words);
+}
+
 extern "C" int vings_surfel_set_tight_binning(int on) {
     return g_tight_binning.exchange(on ? 1 : 0);
 }
@@ -703,7 +733,7 @@ static int project_backward_finish(
     int64_t* kf_id, int64_t this_kf, int bookkeeping, float* g_xyz, float* g_rgb, float* g_opacity,
     float* g_scaling, float* g_rotation, uint8_t* visible, float* scores_grad, float* packed,
     int64_t* record_keys, const int32_t* slot_of_row, int32_t* rows_of_slot, int chunk_rows,
-    void* stream) {
+    void* stream, const uint32_t* guard_count = nullptr, uint32_t guard_limit = 0u) {
     VINGS_REQUIRE(N >= 0 && H > 0 && W > 0, "sizes");
     if (N == 0) return VINGS_OK;
     VINGS_REQUIRE(means3D && scales && rotations && viewmatrix && projmatrix && radii && dgeom &&
@@ -730,7 +760,8 @@ static int project_backward_finish(
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PROF_PROJECT_BWD, s);
     project_bwd_finish_kernel<<<cdiv(N, 256), 256, 0, s>>>(
-        N, H, W, scale_modifier, means3D, rotations, viewmatrix, projmatrix, dgeom, a, scores_grad);
+        N, H, W, scale_modifier, means3D, rotations, viewmatrix, projmatrix, dgeom, a, scores_grad,
+        guard_count, guard_limit);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }
@@ -766,4 +797,21 @@ extern "C" int vings_surfel_project_backward_pack(
                                    this_kf, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                                    scores_grad, packed, record_keys, slot_of_row, rows_of_slot,
                                    chunk_rows, stream);
+}
+
+extern "C" int vings_surfel_project_backward_finish_guarded(
+    int N, int H, int W, float scale_modifier, const float* means3D, const float* scales,
+    const float* rotations, const float* viewmatrix, const float* projmatrix, const int32_t* radii,
+    const float* dgeom, const float* opacities, const float* raw_rotation,
+    const uint8_t* stable_mask, float* global_scores, float* local_scores, float* kf_max_scores,
+    int64_t* kf_id, int64_t this_kf, float* g_xyz, float* g_rgb, float* g_opacity,
+    float* g_scaling, float* g_rotation, uint8_t* visible, const uint32_t* instance_count,
+    uint32_t capacity, void* stream) {
+    VINGS_REQUIRE(instance_count != nullptr, "instance_count");
+    return project_backward_finish(N, H, W, scale_modifier, means3D, scales, rotations, viewmatrix,
+                                   projmatrix, radii, dgeom, opacities, raw_rotation, stable_mask,
+                                   global_scores, local_scores, kf_max_scores, kf_id, this_kf, 1,
+                                   g_xyz, g_rgb, g_opacity, g_scaling, g_rotation, visible, nullptr,
+                                   nullptr, nullptr, nullptr, nullptr, 0, stream, instance_count,
+                                   capacity);
 }

@@ -386,6 +386,117 @@ class SurfelMapper:
         self._last_radii = st.radii
         return loss_vec
 
+    # ------------------------------------------------------------------ view step as a HIP graph
+    def _fused_view_fixed(self, settings, intr, gt, Rw2c_host, kf_id, capacity, count_words):
+        """`fused_view` (single GPU) in the form a stream capture can record: fixed instance
+        capacity, no host wait, and a finish + Adam that skip the whole step on the device if
+        the view's instance count exceeds the capacity."""
+        from . import _lib, surfel
+        L = _lib.lib()
+        fb = self._fused_buffers()
+        P, n, dev = self.params, self.n, self.device
+        stream = _lib.stream_ptr(dev)
+        ptr = _lib.ptr
+        with torch.no_grad():
+            xyz, rgb = P["_xyz"].detach(), P["_rgb"].detach()
+            dgeom = torch.empty((n, surfel.GRAD_STRIDE), dtype=torch.float32, device=dev)
+            st, aux = surfel.rasterize_forward_fixed(
+                xyz, rgb, fb["opac"], fb["scales"], fb["rot"], settings,
+                (P["_opacity"].detach(), P["_scaling"].detach(), P["_rotation"].detach()), dgeom,
+                capacity, count_words)
+            loss_vec, d_rgb, d_allmap = mapping_loss_hip(st.color, st.allmap, gt, Rw2c_host, intr,
+                                                         self.loss_weights)
+            g = fb["grads"]
+            view, proj = aux[0], aux[1]
+            surfel.blend_backward(st, aux, d_rgb, d_allmap, dgeom=dgeom)
+            count_ptr = st.tail_ptr + 8                    # third count word: D
+            _lib.check(L.vings_surfel_project_backward_finish_guarded(
+                n, st.H, st.W, 1.0, ptr(xyz), ptr(fb["scales"]), ptr(fb["rot"]), ptr(view),
+                ptr(proj), ptr(st.radii), ptr(dgeom), ptr(fb["opac"]), ptr(P["_rotation"]),
+                ptr(self.stable_mask.view(torch.uint8)), ptr(self.global_scores),
+                ptr(self.local_scores), ptr(self.globalkf_max_scores), ptr(self.globalkf_id),
+                int(kf_id), ptr(g["_xyz"]), ptr(g["_rgb"]), ptr(g["_opacity"]), ptr(g["_scaling"]),
+                ptr(g["_rotation"]), ptr(fb["vis"]), count_ptr, int(capacity), stream),
+                "vings_surfel_project_backward_finish_guarded")
+            self.optimizer.step(fb["vis"], n, guard=(count_ptr, capacity))
+        return loss_vec, st
+
+    def _graph_signature(self, settings, gt):
+        """Everything a captured view step has baked in by address: a change (map maintenance
+        replaces the parameter and moment arrays, a new keyframe brings new images) makes the
+        graph stale."""
+        sig = [self.n]
+        for k in self.NAMES:
+            p = self.params[k]
+            st = self.optimizer.state.get(p, {})
+            sig += [p.data_ptr(), st["exp_avg"].data_ptr() if "exp_avg" in st else 0]
+        sig += [t.data_ptr() for t in (self.global_scores, self.local_scores, self.stable_mask,
+                                       self.globalkf_id, self.globalkf_max_scores)]
+        sig += [gt[k].data_ptr() for k in ("rgb", "depth", "depth_cov")]
+        sig += [settings.viewmatrix.data_ptr(), settings.projmatrix.data_ptr()]
+        sig += [float(g["lr"]) for g in self.optimizer.param_groups]
+        return tuple(sig)
+
+    def fused_view_graphed(self, key, settings, intr, gt, Rw2c_host, kf_id=0):
+        """`fused_view` of keyframe `key`, replayed from a HIP graph (single GPU).  The mapper
+        optimises the keyframes of its window over and over (gaussian_base.py:353-404 runs
+        once per iteration per keyframe); the ~25 launches of a view step differ between two
+        iterations of the same keyframe in nothing but the data, so they are captured once per
+        keyframe and replayed, which removes the launch gaps and the host work between them.
+
+        The first call for a key runs the plain step (and learns the instance count), the second
+        captures the step with room for 1/8 more instances, later calls replay.  `settings`,
+        `gt` and the parameter arrays are baked in by address: pass the same tensors every time
+        (a changed address, splat count or learning rate re-captures).  Should a replayed view
+        ever produce more instances than its graph has room for, that replay leaves the map
+        untouched (the guarded kernels drop the step); it is noticed at the next call for the
+        key, which repeats the dropped step eagerly before it re-captures.
+        Returns the loss vector of the step (device tensor; of the repeated step in that case)."""
+        graphs = self.__dict__.setdefault("_view_graphs", {})
+        sig = self._graph_signature(settings, gt)
+        ent = graphs.get(key)
+        retired = None
+        if ent is not None and ent.get("sig") != sig:
+            # (a retired graph is kept until its successor is captured: the graphs of a mapper
+            # share one memory pool, which must not lose its last user in between)
+            retired, ent = ent.get("graph") or ent.get("retired"), None
+        from . import surfel
+        if ent is None:
+            loss_vec = self.fused_view(settings, intr, gt, Rw2c_host, kf_id)
+            graphs[key] = {"sig": self._graph_signature(settings, gt), "graph": None,
+                           "retired": retired, "D": int(surfel.LAST_INSTANCE_COUNT)}
+            return loss_vec
+        if ent["graph"] is not None:
+            # the replay of one window ago has long finished; its count tells whether it fit
+            ent["event"].synchronize()
+            d_prev = int(ent["count"][2])
+            if d_prev > ent["capacity"]:
+                self.fused_view(settings, intr, gt, Rw2c_host, kf_id)     # the dropped step
+                ent["retired"], ent["graph"] = ent["graph"], None
+                ent["D"] = int(surfel.LAST_INSTANCE_COUNT)
+                ent["sig"] = self._graph_signature(settings, gt)
+            elif d_prev > 0.97 * ent["capacity"]:
+                ent["retired"], ent["graph"] = ent["graph"], None         # growing: more room
+                ent["D"] = d_prev
+        if ent["graph"] is None:
+            cap = ent["D"] + ent["D"] // 8 + 4096
+            count = torch.zeros(4, dtype=torch.int32).pin_memory()
+            pool = self.__dict__.get("_view_graph_pool")
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize(self.device)
+            with torch.cuda.graph(g, pool=pool):
+                loss_vec, st = self._fused_view_fixed(settings, intr, gt, Rw2c_host, kf_id, cap, count)
+            if pool is None:
+                self._view_graph_pool = g.pool()       # the graphs of a window share their memory
+            ent.update(graph=g, capacity=cap, count=count, loss=loss_vec, radii=st.radii,
+                       event=torch.cuda.Event(), retired=None)
+        ent["graph"].replay()
+        ent["event"].record()
+        self.last_loss = ent["loss"][0]
+        self.last_loss_terms = ent["loss"]
+        self._last_radii = ent["radii"]
+        return ent["loss"]
+
     _WIDTHS = (3, 3, 1, 2, 4)
 
     def _exchange_compact(self, L, reducer, st, xyz, fb, view, proj, dgeom, kf_id, stream):

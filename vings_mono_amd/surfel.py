@@ -53,7 +53,7 @@ class SurfelForwardState:
     """Device buffers produced by one forward pass (kept for backward / tests)."""
     __slots__ = ("N", "H", "W", "D", "geom", "depth", "radii", "rect", "tiles_touched",
                  "block_prefix", "keys", "vals", "ranges", "final_T", "n_contrib", "color",
-                 "allmap")
+                 "allmap", "tail_ptr", "_keep")
 
 
 def set_tight_binning(on):
@@ -238,6 +238,71 @@ def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys,
     return st, aux
 
 
+def rasterize_forward_fixed(means3D, colors, opacities, scales, rotations, settings, raw, dgeom,
+                            capacity, count_words):
+    """The forward pass of `rasterize_forward(raw=..., dgeom=...)` with nothing in it that a
+    stream capture cannot record: the instance list is binned into buffers of `capacity`
+    entries and the host does not wait for the count.  The projection leaves {depth bits min,
+    max, instance count D} in `count_words` (uint32 [>=3], pinned host memory or device memory);
+    the result is only valid if D <= capacity, which the CALLER checks later (and the guarded
+    finish / Adam entry points check on the device)."""
+    L = _lib.lib()
+    dev = means3D.device
+    N = means3D.shape[0]
+    H, W = int(settings.image_height), int(settings.image_width)
+    if N == 0 or capacity <= 0:
+        raise _lib.VingsError("rasterize_forward_fixed needs splats and a positive capacity")
+    st = SurfelForwardState()
+    st.N, st.H, st.W = N, H, W
+    view = _f32c(settings.viewmatrix, "viewmatrix")
+    proj = _f32c(settings.projmatrix, "projmatrix")
+    bg = _f32c(settings.bg, "bg")
+    flow = settings.u2_minus_u1
+    if flow is not None:
+        flow = _f32c(flow, "u2_minus_u1")
+    mask = settings.pixel_mask
+    if mask is not None:
+        mask = mask.reshape(-1).to(torch.uint8).contiguous()
+    stream = stream_ptr(dev)
+    nb = (N + 255) // 256
+    st.geom = torch.empty((N, GEOM_STRIDE), dtype=torch.float32, device=dev)
+    st.depth = torch.empty(N, dtype=torch.float32, device=dev)
+    st.radii = torch.empty(N, dtype=torch.int32, device=dev)
+    st.rect = torch.empty((N, 4), dtype=torch.int32, device=dev)
+    st.tiles_touched = torch.empty(N, dtype=torch.int32, device=dev)
+    st.block_prefix = torch.empty(3 * nb + 4, dtype=torch.int32, device=dev)
+    T = ((W + TILE - 1) // TILE) * ((H + TILE - 1) // TILE)
+    st.ranges = torch.empty((T, 2), dtype=torch.int32, device=dev)
+    raw_o, raw_s, raw_r = raw
+    check(L.vings_surfel_project_enqueue_activate(
+        N, H, W, float(settings.scale_modifier), ptr(means3D), ptr(raw_s), ptr(raw_r), ptr(raw_o),
+        ptr(colors), ptr(flow), ptr(view), ptr(proj), ptr(scales), ptr(rotations), ptr(opacities),
+        ptr(st.geom), ptr(st.depth), ptr(st.radii), ptr(st.rect), ptr(st.tiles_touched),
+        ptr(st.block_prefix), ptr(dgeom), count_words.data_ptr(), stream),
+        "vings_surfel_project_enqueue_activate")
+    ws_bytes = int(L.vings_surfel_bin_workspace_bytes(capacity))
+    st.keys = torch.empty(capacity, dtype=torch.int64, device=dev)
+    st.vals = torch.empty(capacity, dtype=torch.int32, device=dev)
+    ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
+    tail = st.block_prefix.data_ptr() + 4 * (3 * nb + 1)
+    check(L.vings_surfel_bin_speculative(
+        N, H, W, capacity, 32, tail, ptr(st.depth), ptr(st.rect), ptr(st.tiles_touched),
+        ptr(st.block_prefix), ptr(st.keys), ptr(st.vals), ptr(st.ranges),
+        (ws.data_ptr() + 255) & ~255, ws_bytes, stream), "vings_surfel_bin_speculative")
+    st.color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    st.allmap = torch.empty((AUX_CHANNELS, H, W), dtype=torch.float32, device=dev)
+    st.final_T = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    st.n_contrib = torch.empty((2, H, W), dtype=torch.int32, device=dev)
+    check(L.vings_surfel_blend_forward(H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg),
+                                       ptr(mask), ptr(st.color), ptr(st.allmap), ptr(st.final_T),
+                                       ptr(st.n_contrib), stream), "vings_surfel_blend_forward")
+    st.D = None          # on the device / in count_words only
+    st.keys = None
+    st.tail_ptr = tail   # device address of the count words (for the guarded entry points)
+    st._keep = (ws,)
+    return st, (view, proj, bg, mask, flow)
+
+
 def blend_backward(st, aux, g_color, g_allmap, dgeom=None):
     """Pixel half of the backward pass: the per-splat accumulator rows dgeom [N, GRAD_STRIDE]
     that vings_surfel_project_backward (or its fused _finish form) turns into gradients.
@@ -391,7 +456,9 @@ class SparseGaussianAdam(torch.optim.Adam):
                 (ctypes.c_float * n)(*lrs), b1, b2, eps)
 
     @torch.no_grad()
-    def step(self, visibility, N):
+    def step(self, visibility, N, guard=None):
+        """`guard` = (device address of a view's instance count, capacity): the step does
+        nothing if the count exceeds the capacity (vings_sparse_adam_multi_guarded)."""
         L = _lib.lib()
         _lib.require_gpu_tensor(visibility, "visibility")
         vis = visibility.reshape(-1).to(torch.uint8).contiguous()
@@ -418,6 +485,8 @@ class SparseGaussianAdam(torch.optim.Adam):
             for c0 in range(0, len(items), 8):
                 chunk = items[c0:c0 + 8]
                 n = len(chunk)
+                if guard is not None and any(ptr(t) % 16 for c in chunk for t in c[:4]):
+                    raise _lib.VingsError("the guarded Adam step needs 16-byte aligned arrays")
                 if any(ptr(t) % 16 for c in chunk for t in c[:4]):
                     # the fused launch wants 16-byte aligned arrays (views into a larger
                     # buffer may not be): one launch per group instead
@@ -431,5 +500,10 @@ class SparseGaussianAdam(torch.optim.Adam):
                 VV = (ctypes.c_void_p * n)(*[ptr(c[3]) for c in chunk])
                 WW = (ctypes.c_int * n)(*[c[4] for c in chunk])
                 LR = (ctypes.c_float * n)(*[c[5] for c in chunk])
+                if guard is not None:
+                    check(L.vings_sparse_adam_multi_guarded(
+                        n, PP, GG, MM, VV, WW, LR, ptr(vis), b1, b2, eps, N, guard[0], int(guard[1]),
+                        stream), "vings_sparse_adam_multi_guarded")
+                    continue
                 check(L.vings_sparse_adam_multi(n, PP, GG, MM, VV, WW, LR, ptr(vis), b1, b2, eps,
                                                 N, stream), "vings_sparse_adam_multi")
