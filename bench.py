@@ -52,6 +52,10 @@ def parse():
                     help="skip the reference_api / reference_binning figures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dba", action="store_true")
+    ap.add_argument("--dba-stream", choices=("side", "main"), default="side",
+                    help="side: the window's bundle adjustment runs on a second stream beside its "
+                         "view steps (they share no data; in the reference the tracker's BA and the "
+                         "mapper are separate workers too); main: after them on the same stream")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="all ranks share GPU 0 and exchange over gloo: checks the multi-rank "
                          "path on a one-GPU box; the figure printed is not a benchmark result")
@@ -213,7 +217,16 @@ def main():
     R_host = [w[:3, :3].cpu() for w in w2c_dev]
     cams = [harness.view_settings(w, intr) for w in w2c_dev]
 
+    dba_side = torch.cuda.Stream(device=dev) if (dba is not None and args.dba_stream == "side") else None
+    dba_done = torch.cuda.Event() if dba_side is not None else None
+
     def step(autograd=args.autograd, torch_loss=args.torch_loss, graphed=False):
+        if dba_side is not None:
+            # the window's BA beside its view steps; it starts behind everything already queued
+            dba_side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(dba_side):
+                dba.run()
+                dba_done.record(dba_side)
         for i, k in enumerate(my_views):
             if graphed:
                 mapper.fused_view_graphed(k, cams[i], intr, gts[i], R_host[i], k)
@@ -228,12 +241,14 @@ def main():
         # the record maxima of the window (best keyframe, error score) are merged over the ranks
         # here, once per window, behind the bundle adjustment
         finish_records = mapper.sync_records(reducer, async_op=True)
-        if dba is not None:
+        if dba is not None and dba_side is None:
             dba.run()
         if finish_records is not None:
             finish_records()
         if loop is not None:
             loop_closure()
+        if dba_side is not None:
+            torch.cuda.current_stream(dev).wait_event(dba_done)   # the step ends when both have
 
     def barrier():
         if world > 1:
@@ -346,7 +361,7 @@ def main():
                        "view_step": "autograd" if (args.autograd or args.torch_loss) else "fused C-ABI sequence",
                        "loss": "torch graph" if args.torch_loss else "fused HIP kernels",
                        "splats": args.splats, "width": W, "height": H, "views_per_gpu": V,
-                       "dba": None if dba is None else dba.describe(),
+                       "dba": None if dba is None else dict(dba.describe(), stream=args.dba_stream),
                        "instances_D": stats["D"], "visible": stats["n_vis"],
                        "parallelism": f"views sharded over {world} GPU(s), grad all-reduce",
                        "exchange": None if world == 1 else (
