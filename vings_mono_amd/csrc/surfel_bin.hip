@@ -5,11 +5,12 @@
 //                wavefronts) over the TILE bits only: 2 passes at 1080p (13 tile bits) where
 //                sorting the whole (tile, depth) key took 5 over its 40 differing bits
 //   3. ranges    per-tile ranges from the tile-ordered keys
-//   4. depth sort one workgroup per tile orders its list in LDS by (depth bits, splat index)
-//                (bitonic network, the exchanges below 64 entries as lane exchanges in
-//                registers; lists beyond the LDS capacity: LDS-sorted runs + merge passes
-//                through the free half of the radix sort's ping-pong buffers)
-// 9 launches instead of 17; 0.17 ms instead of 0.25 ms for the 2.4 M instances of a 1080p view.
+//   4. depth sort one workgroup per tile orders its list in LDS by (depth bits, splat index):
+//                a sample sort (bisection over 64 ordered sample keys, LDS counters, rank
+//                among the few bucket mates), a bitonic network below 129 entries and for the
+//                sample; lists beyond the LDS capacity: LDS-sorted runs + merge passes through
+//                the free half of the radix sort's ping-pong buffers
+// 9 launches instead of 17; 0.146 ms instead of 0.25 ms for the 2.4 M instances of a 1080p view.
 //
 // The order is fully determined: a splat emits at most one instance per tile and instances
 // are emitted in splat order, so a stable sort by (tile, depth) equals ordering every tile's
@@ -35,7 +36,7 @@ constexpr int kSortTile = kSortThreads * kSortItems;  // 2048 keys per workgroup
 constexpr int kRadixBits = 8;
 constexpr int kRadix = 1 << kRadixBits;
 constexpr int kMaxPasses = 4;
-constexpr int kSortCap = 2048;          // composites one LDS depth sort holds (16 KB: eight workgroups a CU)
+constexpr int kSortCap = 1024;          // composites one LDS depth sort holds (8 + 8 KB of LDS)
 
 // ---------------------------------------------------------------------------
 // duplicate with keys: lane i owns splat i; its output offset is the
@@ -334,49 +335,122 @@ __device__ __forceinline__ void bitonic_lds(uint64_t* s, int P) {
     }
 }
 
+// Ascending order of the n <= kSortCap composites in s[0 .. n), 256 lanes; the result is left in
+// s.  Lists of up to 128 entries go through the bitonic network.  Longer ones are sample-sorted,
+// which costs a fifth of the network's compare-exchanges at the usual 300 entries: a strided
+// sample of 64 (256 beyond 512 entries) keys is ordered by the network and cuts the key range
+// into buckets of a few entries each; every entry finds its bucket by bisection over the
+// sample, takes a place in it with an LDS counter, is moved next to its bucket mates, and its
+// final position is the bucket's first slot plus the number of mates below it.  The composites
+// are distinct, so buckets stay small whatever the depth distribution is (a strided sample of
+// an already ordered list is the ideal sample); a bad sample costs time, never the order.
+struct SortShared {
+    uint64_t s[kSortCap];
+    uint64_t grp[kSortCap];
+    uint64_t spl[256];
+    uint32_t cnt[256];
+    uint32_t start[256];
+    uint32_t wtot[4];
+};
+
+__device__ __forceinline__ void lds_sort(SortShared& sh, uint32_t n) {
+    if (n <= 128u) {
+        const int P = n <= 64u ? 64 : 128;
+        for (uint32_t i = n + threadIdx.x; i < (uint32_t)P; i += 256) sh.s[i] = ~0ull;
+        __syncthreads();
+        bitonic_lds(sh.s, P);
+        return;
+    }
+    const int NB = n <= 512u ? 64 : 256;
+    if ((int)threadIdx.x < NB) {
+        sh.spl[threadIdx.x] = sh.s[(threadIdx.x * n) / (uint32_t)NB];
+        sh.cnt[threadIdx.x] = 0u;
+    }
+    __syncthreads();
+    bitonic_lds(sh.spl, NB);
+    constexpr int kRounds = kSortCap / 256;
+    uint64_t e[kRounds];
+    uint32_t bk[kRounds], pos[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        const uint32_t i = r * 256 + threadIdx.x;
+        if (i < n) {
+            e[r] = sh.s[i];
+            int lo = 0;                            // largest j with spl[j] <= e (0 if none)
+            for (int step = NB >> 1; step > 0; step >>= 1)
+                if (sh.spl[lo + step] <= e[r]) lo += step;
+            bk[r] = (uint32_t)lo;
+            pos[r] = atomicAdd(&sh.cnt[lo], 1u);
+        }
+    }
+    __syncthreads();
+    {   // exclusive scan of the bucket counts (one per lane)
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const uint32_t v = (int)threadIdx.x < NB ? sh.cnt[threadIdx.x] : 0u;
+        const uint32_t inc = wave_scan_incl(v);
+        if (lane == 63) sh.wtot[w] = inc;
+        __syncthreads();
+        uint32_t off = inc - v;
+        for (int k = 0; k < w; ++k) off += sh.wtot[k];
+        sh.start[threadIdx.x] = off;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r)
+        if (r * 256 + threadIdx.x < n) sh.grp[sh.start[bk[r]] + pos[r]] = e[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        if (r * 256 + threadIdx.x < n) {
+            const uint32_t b0 = sh.start[bk[r]], c = sh.cnt[bk[r]];
+            uint32_t rank = b0;
+            for (uint32_t q = b0; q < b0 + c; ++q) rank += sh.grp[q] < e[r] ? 1u : 0u;
+            sh.s[rank] = e[r];
+        }
+    }
+    __syncthreads();
+}
+
 // One workgroup per tile: orders the tile's list by (depth bits, splat index), in place.  The
 // list arrives in splat order (the radix passes are stable), keys = tile << 32 | depth bits.
-constexpr int kCap = kSortCap;
 __global__ __launch_bounds__(256) void tile_depth_sort_kernel(
     const uint32_t* __restrict__ ranges, uint64_t* keys, uint32_t* vals, uint64_t* scratch) {
-    __shared__ uint64_t s[kCap];
+    __shared__ SortShared sh;
     const uint32_t t = blockIdx.x;
     const uint2 rg = reinterpret_cast<const uint2*>(ranges)[t];
     const uint32_t b = rg.x, n = rg.y - rg.x;
     if (n < 2u) return;                      // a list of one entry is in order as it is
     const uint64_t tile_hi = (uint64_t)t << 32;
-    if (n <= (uint32_t)kCap) {
-        int P = 64;
-        while ((uint32_t)P < n) P <<= 1;
-        for (int i = threadIdx.x; i < P; i += 256)
-            s[i] = (uint32_t)i < n ? ((keys[b + i] << 32) | (uint64_t)vals[b + i]) : ~0ull;
+    if (n <= (uint32_t)kSortCap) {
+        for (uint32_t i = threadIdx.x; i < n; i += 256)
+            sh.s[i] = (keys[b + i] << 32) | (uint64_t)vals[b + i];
         __syncthreads();
-        bitonic_lds(s, P);
+        lds_sort(sh, n);
         for (uint32_t i = threadIdx.x; i < n; i += 256) {
-            const uint64_t c = s[i];
+            const uint64_t c = sh.s[i];
             keys[b + i] = tile_hi | (c >> 32);
             vals[b + i] = (uint32_t)c;
         }
         return;
     }
-    // A list the LDS does not hold: runs of kCap composites sorted in LDS and parked in the
+    // A list the LDS does not hold: runs of kSortCap composites sorted in LDS and parked in the
     // scratch buffer, then merged pairwise, alternating between the scratch buffer and the
     // tile's own stretch of the key array (all of its keys have been read by then); every pair
     // of runs is cut into 256 equal output pieces along its merge path.
     uint64_t* A = scratch + b;
     uint64_t* B = keys + b;
-    for (uint32_t r0 = 0; r0 < n; r0 += kCap) {
-        const uint32_t len = min((uint32_t)kCap, n - r0);
-        for (uint32_t i = threadIdx.x; i < (uint32_t)kCap; i += 256)
-            s[i] = i < len ? ((B[r0 + i] << 32) | (uint64_t)vals[b + r0 + i]) : ~0ull;
+    for (uint32_t r0 = 0; r0 < n; r0 += kSortCap) {
+        const uint32_t len = min((uint32_t)kSortCap, n - r0);
+        for (uint32_t i = threadIdx.x; i < len; i += 256)
+            sh.s[i] = (B[r0 + i] << 32) | (uint64_t)vals[b + r0 + i];
         __syncthreads();
-        bitonic_lds(s, kCap);
-        for (uint32_t i = threadIdx.x; i < len; i += 256) A[r0 + i] = s[i];
+        lds_sort(sh, len);
+        for (uint32_t i = threadIdx.x; i < len; i += 256) A[r0 + i] = sh.s[i];
         __syncthreads();
     }
     uint64_t* src = A;
     uint64_t* dst = B;
-    for (uint32_t R = kCap; R < n; R <<= 1) {
+    for (uint32_t R = kSortCap; R < n; R <<= 1) {
         for (uint32_t p0 = 0; p0 < n; p0 += 2 * R) {
             const uint32_t la = min(R, n - p0);
             const uint32_t lb = n - p0 - la < R ? n - p0 - la : R;
