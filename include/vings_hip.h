@@ -509,6 +509,22 @@ int vings_mapping_loss(int H, int W, const float* rgb, const float* allmap, cons
                        float fu, float fv, float cu, float cv, const float* weights_host,
                        float* dL_drgb, float* dL_dallmap, float* loss_out, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* The same with the parts that depend on the keyframe's ground truth alone kept between calls
+ * (the mapper iterates over a keyframe many times, gaussian_base.py:353-404, while its images
+ * stay what they are): the Gaussian-filtered mean and second moment of gt_rgb, the pixel
+ * classes (valid / sky) and their counts.  gt_cache: vings_mapping_loss_gt_cache_bytes(H, W)
+ * bytes of device memory owned by the caller, 8-byte aligned, one per keyframe.
+ * gt_cache_valid = 0: computed as in vings_mapping_loss and stored; 1: read (the SSIM forward
+ * pass then filters three moments instead of five).  Results are bit-identical to
+ * vings_mapping_loss either way.  The caller resets the flag when it changes gt_rgb / gt_depth. */
+size_t vings_mapping_loss_gt_cache_bytes(int H, int W);
+int vings_mapping_loss_cached(int H, int W, const float* rgb, const float* allmap,
+                              const float* gt_rgb, const float* gt_depth,
+                              const float* gt_depth_cov, const float* Rw2c_host, float fu, float fv,
+                              float cu, float cv, const float* weights_host, float* dL_drgb,
+                              float* dL_dallmap, float* loss_out, void* workspace,
+                              size_t workspace_bytes, void* gt_cache, int gt_cache_valid,
+                              void* stream);
 
 /* ========================================================================
  * Dense bundle adjustment (droid_backends).

@@ -100,6 +100,34 @@ def test_loss_and_gradients_tiny_image():
     _check(5, 7, 11)            # smaller than the SSIM window: padding everywhere
 
 
+@pytest.mark.parametrize("H,W", [(131, 250), (1080, 1920)])
+def test_ground_truth_cache_gives_the_same_bits(H, W):
+    """vings_mapping_loss_cached (filtered ground-truth moments, pixel classes and counts kept
+    per keyframe) against vings_mapping_loss: the filling call and two reading calls with
+    different renders, every output bit-identical; a new ground-truth image refills."""
+    dev = torch.device("cuda:0")
+    rgb, allmap, gt, w2c, intr = _inputs(H, W, 23)
+    gt = {k: v.to(dev) for k, v in gt.items()}
+    renders = [(rgb.to(dev), allmap.to(dev))]
+    for seed in (24, 25):
+        r2, a2, _, _, _ = _inputs(H, W, seed)
+        renders.append((r2.to(dev), a2.to(dev)))
+    for i, (r, a) in enumerate(renders):
+        want = harness.mapping_loss_hip(r, a, gt, w2c[:3, :3], intr, WEIGHTS)
+        got = harness.mapping_loss_hip(r, a, gt, w2c[:3, :3], intr, WEIGHTS, cache=True)
+        torch.cuda.synchronize()
+        for x, y in zip(want, got):
+            assert torch.equal(x, y), i
+    tag = gt["_loss_cache"][0]
+    gt["rgb"] = gt["rgb"].flip(2).contiguous()                     # another image, another address
+    want = harness.mapping_loss_hip(*renders[0], {k: gt[k] for k in ("rgb", "depth", "depth_cov")},
+                                    w2c[:3, :3], intr, WEIGHTS)
+    got = harness.mapping_loss_hip(*renders[0], gt, w2c[:3, :3], intr, WEIGHTS, cache=True)
+    assert gt["_loss_cache"][0] != tag
+    for x, y in zip(want, got):
+        assert torch.equal(x, y)
+
+
 def test_no_sky_no_valid_masks_do_not_divide_by_zero():
     vec = _check(40, 50, 7, sky_frac=0.0, hole_frac=0.0)
     assert float(vec[7]) == 0.0 and float(vec[3]) == 0.0

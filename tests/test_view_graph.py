@@ -97,7 +97,7 @@ def test_new_addresses_recapture():
     b.fused_view_graphed(0, cam, intr, gt, R, 0)
     g0 = b._view_graphs[0]["graph"]
     assert g0 is not None
-    gt2 = {k: v.clone() for k, v in gt.items()}                  # a new keyframe image
+    gt2 = {k: gt[k].clone() for k in ("rgb", "depth", "depth_cov")}   # a new keyframe image
     b.fused_view_graphed(0, cam, intr, gt2, R, 0)                # eager again
     assert b._view_graphs[0]["graph"] is None
     b.fused_view_graphed(0, cam, intr, gt2, R, 0)

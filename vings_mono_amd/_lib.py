@@ -82,6 +82,10 @@ _SIGNATURES = {
     "vings_mapping_loss": (_c.c_int, [_c.c_int, _c.c_int] + [_P] * 5 +
                            [_c.POINTER(_c.c_float)] + [_c.c_float] * 4 +
                            [_c.POINTER(_c.c_float)] + [_P] * 4 + [_c.c_size_t, _P]),
+    "vings_mapping_loss_gt_cache_bytes": (_c.c_size_t, [_c.c_int, _c.c_int]),
+    "vings_mapping_loss_cached": (_c.c_int, [_c.c_int, _c.c_int] + [_P] * 5 +
+                                  [_c.POINTER(_c.c_float)] + [_c.c_float] * 4 +
+                                  [_c.POINTER(_c.c_float)] + [_P] * 4 + [_c.c_size_t, _P, _c.c_int, _P]),
 }
 
 _lib = None

@@ -143,13 +143,19 @@ _LOSS_WS = {}
 LOSS_WEIGHT_ORDER = ("rgb_loss", "depth_loss", "alpha_loss", "normal_loss", "dist_loss")
 
 
-def mapping_loss_hip(rgb, allmap, gt, Rw2c_host, intr, weights=DEFAULT_LOSS_WEIGHTS):
+def mapping_loss_hip(rgb, allmap, gt, Rw2c_host, intr, weights=DEFAULT_LOSS_WEIGHTS, cache=False):
     """`mapping_loss(postprocess(...))` and its gradient w.r.t. the rasteriser outputs in
     four HIP launches (csrc/mapping_loss.hip) instead of a PyTorch graph.
 
     rgb [3,H,W], allmap [9,H,W]: rasteriser outputs (device); gt: dict with rgb [3,H,W],
     depth [1,H,W], depth_cov [1,H,W]; Rw2c_host: 3x3 CPU tensor (rotation of w2c).
     Returns (loss_vec [8] device tensor, dL_drgb, dL_dallmap); loss_vec[0] is the total.
+
+    cache=True keeps what depends on the ground truth alone (filtered moments of gt["rgb"],
+    pixel classes, their counts) in gt["_loss_cache"] between calls, which is what the mapper
+    wants while it iterates over a keyframe.  The entry is tied to the addresses of gt["rgb"] /
+    gt["depth"]; a caller that overwrites those images IN PLACE drops it with
+    `gt.pop("_loss_cache", None)`.  Same bits with and without.
     """
     from . import _lib
     import ctypes
@@ -170,11 +176,22 @@ def mapping_loss_hip(rgb, allmap, gt, Rw2c_host, intr, weights=DEFAULT_LOSS_WEIG
     wts = (ctypes.c_float * 5)(*[float(weights[k]) for k in LOSS_WEIGHT_ORDER])
     gt_rgb, gt_depth, gt_cov = (gt["rgb"].contiguous(), gt["depth"].contiguous(),
                                 gt["depth_cov"].contiguous())
-    _lib.check(lib.vings_mapping_loss(
-        H, W, _lib.ptr(rgb.contiguous()), _lib.ptr(allmap.contiguous()), _lib.ptr(gt_rgb),
-        _lib.ptr(gt_depth), _lib.ptr(gt_cov), R, float(intr["fu"]), float(intr["fv"]),
-        float(intr["cu"]), float(intr["cv"]), wts, _lib.ptr(d_rgb), _lib.ptr(d_allmap),
-        _lib.ptr(loss_vec), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "vings_mapping_loss")
+    args = (H, W, _lib.ptr(rgb.contiguous()), _lib.ptr(allmap.contiguous()), _lib.ptr(gt_rgb),
+            _lib.ptr(gt_depth), _lib.ptr(gt_cov), R, float(intr["fu"]), float(intr["fv"]),
+            float(intr["cu"]), float(intr["cv"]), wts, _lib.ptr(d_rgb), _lib.ptr(d_allmap),
+            _lib.ptr(loss_vec), _lib.ptr(ws), ws.numel())
+    if cache:
+        tag = (gt_rgb.data_ptr(), gt_depth.data_ptr(), H, W)
+        ent = gt.get("_loss_cache")
+        valid = ent is not None and ent[0] == tag
+        if not valid:
+            ent = (tag, torch.empty(int(lib.vings_mapping_loss_gt_cache_bytes(H, W)),
+                                    dtype=torch.uint8, device=dev))
+            gt["_loss_cache"] = ent
+        _lib.check(lib.vings_mapping_loss_cached(*args, _lib.ptr(ent[1]), 1 if valid else 0,
+                                                 _lib.stream_ptr(dev)), "vings_mapping_loss_cached")
+    else:
+        _lib.check(lib.vings_mapping_loss(*args, _lib.stream_ptr(dev)), "vings_mapping_loss")
     return loss_vec, d_rgb, d_allmap
 
 
@@ -353,7 +370,7 @@ class SurfelMapper:
                 # on; agreed between the ranks on a side stream while this one goes on
                 reducer.start_union(st.radii)
             loss_vec, d_rgb, d_allmap = mapping_loss_hip(st.color, st.allmap, gt, Rw2c_host, intr,
-                                                         self.loss_weights)
+                                                         self.loss_weights, cache=True)
             g = fb["grads"]
             view, proj = aux[0], aux[1]
             surfel.blend_backward(st, aux, d_rgb, d_allmap, dgeom=dgeom)
@@ -405,7 +422,7 @@ class SurfelMapper:
                 (P["_opacity"].detach(), P["_scaling"].detach(), P["_rotation"].detach()), dgeom,
                 capacity, count_words)
             loss_vec, d_rgb, d_allmap = mapping_loss_hip(st.color, st.allmap, gt, Rw2c_host, intr,
-                                                         self.loss_weights)
+                                                         self.loss_weights, cache=True)
             g = fb["grads"]
             view, proj = aux[0], aux[1]
             surfel.blend_backward(st, aux, d_rgb, d_allmap, dgeom=dgeom)
