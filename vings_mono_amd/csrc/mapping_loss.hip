@@ -73,7 +73,7 @@ constexpr uint8_t kPixValid = 1, kPixSky = 2;
 // instead of three).  Bit-identical results in all modes (every moment has its own chain of
 // multiply-adds).
 template <int kMode>
-__global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, Gauss gw,
+__global__ __launch_bounds__(256, kMode == 2 ? 4 : 3) void ssim_fwd_kernel(int H, int W, Gauss gw,
                                                        const float* __restrict__ rgb,
                                                        const float* __restrict__ gt_rgb,
                                                        const float* __restrict__ gt_depth,
@@ -112,20 +112,38 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, Gauss gw,
             }
         }
     }
-    for (int ch = 0; ch < 3; ++ch) {
+    // The tile of a channel (42 x 42 values of both images, seven per lane) is fetched into
+    // registers while the previous channel is being filtered, so that only the first fetch of a
+    // workgroup waits for memory.
+    constexpr int kFetch = (kSIn * kSIn + 255) / 256;
+    float fxv[kFetch], fyv[kFetch];
+    auto fetch = [&](int ch) {
         const float* __restrict__ X = rgb + ch * HW;
         const float* __restrict__ Y = gt_rgb + ch * HW;
-        for (int idx = threadIdx.x; idx < kSIn * kSIn; idx += 256) {
+#pragma unroll
+        for (int k = 0; k < kFetch; ++k) {
+            const int idx = k * 256 + threadIdx.x;
             const int r = idx / kSIn, cc = idx - r * kSIn;
             const int gy = ty0 + r - kHalo, gx = tx0 + cc - kHalo;
-            float xv = 0.f, yv = 0.f;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                xv = X[(size_t)gy * W + gx];
-                yv = Y[(size_t)gy * W + gx];
+            fxv[k] = 0.f; fyv[k] = 0.f;
+            if (idx < kSIn * kSIn && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                fxv[k] = X[(size_t)gy * W + gx];
+                fyv[k] = Y[(size_t)gy * W + gx];
             }
-            sx[r][cc] = xv; sy[r][cc] = yv;
+        }
+    };
+    fetch(0);
+    for (int ch = 0; ch < 3; ++ch) {
+#pragma unroll
+        for (int k = 0; k < kFetch; ++k) {
+            const int idx = k * 256 + threadIdx.x;
+            if (idx < kSIn * kSIn) {
+                const int r = idx / kSIn, cc = idx - r * kSIn;
+                sx[r][cc] = fxv[k]; sy[r][cc] = fyv[k];
+            }
         }
         __syncthreads();
+        if (ch < 2) fetch(ch + 1);
         // horizontal pass: a lane produces 4 neighbouring columns of one row from 14 reads
         for (int idx = threadIdx.x; idx < kSIn * (kST / 4); idx += 256) {
             const int r = idx >> 3, c0 = (idx & 7) * 4;
@@ -260,17 +278,34 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, Gauss gw, f
             vld[i] = cls[p] == kPixValid;
         }
     }
-    for (int ch = 0; ch < 3; ++ch) {
-        for (int idx = threadIdx.x; idx < kSIn * kSIn; idx += 256) {
+    // (tiles fetched one channel ahead, as in ssim_fwd_kernel)
+    constexpr int kFetch = (kSIn * kSIn + 255) / 256;
+    float fm[3][kFetch];
+    auto fetch = [&](int ch) {
+#pragma unroll
+        for (int k = 0; k < kFetch; ++k) {
+            const int idx = k * 256 + threadIdx.x;
             const int r = idx / kSIn, cc = idx - r * kSIn;
             const int gy = ty0 + r - kHalo, gx = tx0 + cc - kHalo;
-            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const bool in = idx < kSIn * kSIn && gy >= 0 && gy < H && gx >= 0 && gx < W;
             const size_t p = in ? (size_t)gy * W + gx : 0;
 #pragma unroll
-            for (int m = 0; m < 3; ++m)
-                sm[m][r][cc] = in ? maps[(size_t)(3 * ch + m) * HW + p] : 0.f;
+            for (int m = 0; m < 3; ++m) fm[m][k] = in ? maps[(size_t)(3 * ch + m) * HW + p] : 0.f;
+        }
+    };
+    fetch(0);
+    for (int ch = 0; ch < 3; ++ch) {
+#pragma unroll
+        for (int k = 0; k < kFetch; ++k) {
+            const int idx = k * 256 + threadIdx.x;
+            if (idx < kSIn * kSIn) {
+                const int r = idx / kSIn, cc = idx - r * kSIn;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) sm[m][r][cc] = fm[m][k];
+            }
         }
         __syncthreads();
+        if (ch < 2) fetch(ch + 1);
         // both passes as sliding windows: 14 reads feed 4 neighbouring outputs
         for (int idx = threadIdx.x; idx < kSIn * (kST / 4); idx += 256) {
             const int r = idx >> 3, c0 = (idx & 7) * 4;
