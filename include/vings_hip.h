@@ -287,6 +287,25 @@ int vings_surfel_project_backward_finish(
     int64_t* record_keys, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Blend passes of the mapper's own view step.  Its loss (loss_utils.py:110-153 as called at
+ * gaussian_base.py:367-382) has no term in the median depth nor in the blended flow, and the
+ * mapper attaches no flow to its splats, so dL/dallmap[5], [7], [8] are identically zero.
+ * The lean forward writes zeros into those three planes and 0 as the median's contributor
+ * index, the lean backward does not read those three gradient planes, and neither does the
+ * per-pair work behind them; every other output has the bits of the full passes.  Arguments as
+ * vings_surfel_blend_forward / vings_surfel_blend_backward_accumulate.  Not for callers that
+ * consume the median depth or the flow (the drop-in GaussianRasterizer uses the full passes). */
+int vings_surfel_blend_forward_lean(int H, int W, const uint32_t* ranges,
+                                    const uint32_t* vals_sorted, const float* geom,
+                                    const float* bg, const uint8_t* pixel_mask, float* out_color,
+                                    float* allmap, float* final_T, uint32_t* n_contrib,
+                                    void* stream);
+int vings_surfel_blend_backward_accumulate_lean(
+    int N, int H, int W, const uint32_t* ranges, const uint32_t* vals_sorted, const float* geom,
+    const float* bg, const uint8_t* pixel_mask, const float* final_T, const uint32_t* n_contrib,
+    const float* dL_dcolor, const float* dL_dallmap, float* dgeom, void* stream);
+
+/* ------------------------------------------------------------------------
  * The view step under HIP stream capture (one graph per keyframe of the window, replayed every
  * iteration).  A graph has fixed buffers, so the view is binned into a fixed capacity, and the
  * host cannot look at the instance count in the middle of it.  Three entry points make that

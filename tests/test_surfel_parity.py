@@ -465,3 +465,51 @@ def test_two_threads_render_on_one_gpu():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_lean_blend_passes_equal_the_full_ones():
+    """The blend passes of the mapper's view step (no median depth, no flow) against the full
+    passes: forward planes bit-identical apart from the three planes written as zeros; the
+    backward pass under upstream gradients that are zero in those planes (as the mapping loss's
+    are) gives the same rows up to the order of its float atomics."""
+    from vings_mono_amd import harness
+    dev = torch.device("cuda:0")
+    W, H, n = 320, 192, 8000
+    raw = {k: v.to(dev).contiguous() for k, v in synth.make_splats(n, W, H, n_views=2, seed=81).items()}
+    intr = synth.intrinsic_for(W, H)
+    cam = harness.view_settings(torch.linalg.inv(synth.window_poses(2)[1]).to(dev), intr)
+    e = lambda *s: torch.empty(*s, device=dev)
+
+    def forward(lean):
+        o, s, r = e(n, 1), e(n, 2), e(n, 4)
+        dgeom = e(n, surfel.GRAD_STRIDE)
+        st, aux = surfel.rasterize_forward(raw["_xyz"], raw["_rgb"], o, s, r, cam,
+                                           raw=(raw["_opacity"], raw["_scaling"], raw["_rotation"]),
+                                           dgeom=dgeom, lean=lean)
+        return st, aux, dgeom
+
+    full, aux_f, dg_f = forward(False)
+    lean, aux_l, dg_l = forward(True)
+    torch.cuda.synchronize()
+    assert torch.equal(full.color, lean.color) and torch.equal(full.final_T, lean.final_T)
+    assert torch.equal(full.n_contrib[0], lean.n_contrib[0]) and int(lean.n_contrib[1].abs().max()) == 0
+    assert int(full.n_contrib[1].max()) > 0 and float(full.allmap[5].abs().max()) > 0
+    for c in range(surfel.AUX_CHANNELS):
+        if c in (5, 7, 8):
+            assert float(lean.allmap[c].abs().max()) == 0.0
+        else:
+            assert torch.equal(full.allmap[c], lean.allmap[c]), c
+    g = torch.Generator(device="cpu").manual_seed(5)
+    g_color = torch.randn(3, H, W, generator=g).to(dev)
+    g_allmap = torch.randn(surfel.AUX_CHANNELS, H, W, generator=g).to(dev)
+    g_allmap[[5, 7, 8]] = 0.0
+    a = surfel.blend_backward(full, aux_f, g_color, g_allmap, dgeom=dg_f)
+    # the lean pass must not even look at the three planes
+    g_poison = g_allmap.clone()
+    g_poison[[5, 7, 8]] = float("nan")
+    b = surfel.blend_backward(lean, aux_l, g_color, g_poison, dgeom=dg_l, lean=True)
+    torch.cuda.synchronize()
+    vis = full.radii > 0
+    assert int(vis.sum()) > 1000 and bool(torch.isfinite(b[vis]).all())
+    scale = a[vis].abs().max(0).values
+    assert bool(((a[vis] - b[vis]).abs().max(0).values <= 1e-5 * scale + 1e-12).all())

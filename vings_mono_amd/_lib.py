@@ -37,6 +37,8 @@ _SIGNATURES = {
     "vings_surfel_bin": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_uint32,
                                     _c.c_uint32] + [_P] * 8 + [_c.c_size_t, _P]),
     "vings_surfel_blend_forward": (_c.c_int, [_c.c_int, _c.c_int] + [_P] * 10),
+    "vings_surfel_blend_forward_lean": (_c.c_int, [_c.c_int, _c.c_int] + [_P] * 10),
+    "vings_surfel_blend_backward_accumulate_lean": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int] + [_P] * 11),
     "vings_surfel_blend_backward": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int] + [_P] * 11),
     "vings_surfel_blend_backward_accumulate": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int] + [_P] * 11),
     "vings_surfel_project_backward": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float] +

@@ -143,6 +143,11 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 // Seven workgroups per CU (72 VGPRs, six of them spilled in the staging code, 20.4 KB of LDS):
 // measured 0.494 ms against 0.504 ms at six; five or four are 5 % and 17 % slower (latency
 // hiding matters more here than the partly filled last round of workgroups).
+// kLean: the view step of the mapper.  Its loss has no term in the median depth nor in the
+// blended flow (dL/dallmap[5], [7], [8] are identically zero, and no flow is attached to the
+// splats), so those three planes are written as zeros and the contributor index of the median
+// as 0, without the per-pair work behind them; every other output keeps its bits.
+template <bool kLean>
 __global__ __launch_bounds__(256, 7) void blend_fwd_kernel(
     int H, int W, int gx, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ vals,
     const float* __restrict__ geom, const float* __restrict__ bg,
@@ -202,12 +207,14 @@ __global__ __launch_bounds__(256, 7) void blend_fwd_kernel(
                 Dd += depth * w;
                 M1 += m1 * w;
                 M2 += m1 * m1 * w;
-                const bool md = c & (T > 0.5f);
-                med = md ? depth : med;
-                medc = md ? contributor : medc;
+                if (!kLean) {
+                    const bool md = c & (T > 0.5f);
+                    med = md ? depth : med;
+                    medc = md ? contributor : medc;
+                    F0 += s.fl[0] * w; F1 += s.fl[1] * w;
+                }
                 N0 += s.n[0] * w; N1 += s.n[1] * w; N2 += s.n[2] * w;
                 C0 += s.rgb[0] * w; C1 += s.rgb[1] * w; C2 += s.rgb[2] * w;
-                F0 += s.fl[0] * w; F1 += s.fl[1] * w;
                 T = c ? test_T : T;
                 last = c ? contributor : last;
             }
@@ -348,6 +355,7 @@ __device__ __forceinline__ void row_mirror_add5(float& a, float& b, float& c, fl
         : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
 }
 
+template <bool kLean>   // kLean: dL/dallmap[5], [7], [8] are zero and not read (see blend_fwd_kernel)
 __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
     int H, int W, int gx, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ vals,
     const float* __restrict__ geom, const float* __restrict__ bg,
@@ -373,7 +381,7 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 
     const uint32_t last = active ? n_contrib[pix] : 0u;
-    const uint32_t medc = active ? n_contrib[HW + pix] : 0u;
+    const uint32_t medc = (!kLean && active) ? n_contrib[HW + pix] : 0u;
     // the deepest contributor over the tile bounds the walk
     uint32_t mx = last;
 #pragma unroll
@@ -393,9 +401,11 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
         gD = dL_dallmap[pix];
         gA = dL_dallmap[HW + pix];
         gN0 = dL_dallmap[2 * HW + pix]; gN1 = dL_dallmap[3 * HW + pix]; gN2 = dL_dallmap[4 * HW + pix];
-        gMed = dL_dallmap[5 * HW + pix];
         gDist = dL_dallmap[6 * HW + pix];
-        gF0 = dL_dallmap[7 * HW + pix]; gF1 = dL_dallmap[8 * HW + pix];
+        if (!kLean) {
+            gMed = dL_dallmap[5 * HW + pix];
+            gF0 = dL_dallmap[7 * HW + pix]; gF1 = dL_dallmap[8 * HW + pix];
+        }
     }
     const float A_final = 1.f - T_final;
     const float bg_dot = bg[0] * gC0 + bg[1] * gC1 + bg[2] * gC2;
@@ -457,7 +467,7 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
             // S = sum over channels of value * dL/dchannel (alpha channel value is 1)
             float S = gA + Wd;
             S += s.rgb[0] * gC0 + s.rgb[1] * gC1 + s.rgb[2] * gC2;
-            S += s.fl[0] * gF0 + s.fl[1] * gF1;
+            if (!kLean) S += s.fl[0] * gF0 + s.fl[1] * gF1;
             S += s.n[0] * gN0 + s.n[1] * gN1 + s.n[2] * gN2;
             S += depth * gD;
             const float Bn = last_alpha * S_last + (1.f - last_alpha) * B;
@@ -466,7 +476,7 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
             S_last = c ? S : S_last;
             last_alpha = c ? alpha : last_alpha;
             float dL_dz = 2.f * w * (m * A_final - M1f) * gDist * dm_dd + w * gD;
-            dL_dz += (c & (pos + 1 == medc)) ? gMed : 0.f;
+            if (!kLean) dL_dz += (c & (pos + 1 == medc)) ? gMed : 0.f;
             float g[kGrad];
             g[11] = w * gN0; g[12] = w * gN1; g[13] = w * gN2;
             g[14] = G * dL_dalpha;
@@ -553,23 +563,44 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
 
 using namespace vings;
 
-extern "C" int vings_surfel_blend_forward(int H, int W, const uint32_t* ranges,
-                                          const uint32_t* vals_sorted, const float* geom,
-                                          const float* bg, const uint8_t* pixel_mask,
-                                          float* out_color, float* allmap, float* final_T,
-                                          uint32_t* n_contrib, void* stream) {
+static int blend_forward_impl(bool lean, int H, int W, const uint32_t* ranges,
+                              const uint32_t* vals_sorted, const float* geom, const float* bg,
+                              const uint8_t* pixel_mask, float* out_color, float* allmap,
+                              float* final_T, uint32_t* n_contrib, void* stream) {
     VINGS_REQUIRE(H > 0 && W > 0, "sizes");
     VINGS_REQUIRE(ranges && bg && out_color && allmap && final_T && n_contrib, "null pointer");
     VINGS_REQUIRE(((uintptr_t)geom & 15) == 0, "geom must be 16-byte aligned");
     const int gx = (W + 15) / 16, gy = (H + 15) / 16;
     ProfScope prof(PROF_BLEND_FWD, (hipStream_t)stream);
-    blend_fwd_kernel<<<gx * gy, 256, 0, (hipStream_t)stream>>>(
-        H, W, gx, ranges, vals_sorted, geom, bg, pixel_mask, out_color, allmap, final_T, n_contrib);
+    if (lean)
+        blend_fwd_kernel<true><<<gx * gy, 256, 0, (hipStream_t)stream>>>(
+            H, W, gx, ranges, vals_sorted, geom, bg, pixel_mask, out_color, allmap, final_T, n_contrib);
+    else
+        blend_fwd_kernel<false><<<gx * gy, 256, 0, (hipStream_t)stream>>>(
+            H, W, gx, ranges, vals_sorted, geom, bg, pixel_mask, out_color, allmap, final_T, n_contrib);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }
 
-static int blend_backward_impl(bool clear, int N, int H, int W, const uint32_t* ranges,
+extern "C" int vings_surfel_blend_forward(int H, int W, const uint32_t* ranges,
+                                          const uint32_t* vals_sorted, const float* geom,
+                                          const float* bg, const uint8_t* pixel_mask,
+                                          float* out_color, float* allmap, float* final_T,
+                                          uint32_t* n_contrib, void* stream) {
+    return blend_forward_impl(false, H, W, ranges, vals_sorted, geom, bg, pixel_mask, out_color,
+                              allmap, final_T, n_contrib, stream);
+}
+
+extern "C" int vings_surfel_blend_forward_lean(int H, int W, const uint32_t* ranges,
+                                               const uint32_t* vals_sorted, const float* geom,
+                                               const float* bg, const uint8_t* pixel_mask,
+                                               float* out_color, float* allmap, float* final_T,
+                                               uint32_t* n_contrib, void* stream) {
+    return blend_forward_impl(true, H, W, ranges, vals_sorted, geom, bg, pixel_mask, out_color,
+                              allmap, final_T, n_contrib, stream);
+}
+
+static int blend_backward_impl(bool clear, bool lean, int N, int H, int W, const uint32_t* ranges,
                                            const uint32_t* vals_sorted, const float* geom,
                                            const float* bg, const uint8_t* pixel_mask,
                                            const float* final_T, const uint32_t* n_contrib,
@@ -584,8 +615,14 @@ static int blend_backward_impl(bool clear, int N, int H, int W, const uint32_t* 
         VINGS_CHECK_HIP(hipMemsetAsync(dgeom, 0, sizeof(float) * (size_t)N * VINGS_GRAD_STRIDE, s));
     const int gx = (W + 15) / 16, gy = (H + 15) / 16;
     ProfScope prof(PROF_BLEND_BWD, s);
-    blend_bwd_kernel<<<gx * gy, 256, 0, s>>>(H, W, gx, ranges, vals_sorted, geom, bg, pixel_mask,
-                                             final_T, n_contrib, dL_dcolor, dL_dallmap, dgeom);
+    if (lean)
+        blend_bwd_kernel<true><<<gx * gy, 256, 0, s>>>(H, W, gx, ranges, vals_sorted, geom, bg,
+                                                       pixel_mask, final_T, n_contrib, dL_dcolor,
+                                                       dL_dallmap, dgeom);
+    else
+        blend_bwd_kernel<false><<<gx * gy, 256, 0, s>>>(H, W, gx, ranges, vals_sorted, geom, bg,
+                                                        pixel_mask, final_T, n_contrib, dL_dcolor,
+                                                        dL_dallmap, dgeom);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }
@@ -618,8 +655,8 @@ extern "C" int vings_surfel_blend_backward(int N, int H, int W, const uint32_t* 
                                            const float* final_T, const uint32_t* n_contrib,
                                            const float* dL_dcolor, const float* dL_dallmap,
                                            float* dgeom, void* stream) {
-    return blend_backward_impl(true, N, H, W, ranges, vals_sorted, geom, bg, pixel_mask, final_T,
-                               n_contrib, dL_dcolor, dL_dallmap, dgeom, stream);
+    return blend_backward_impl(true, false, N, H, W, ranges, vals_sorted, geom, bg, pixel_mask,
+                               final_T, n_contrib, dL_dcolor, dL_dallmap, dgeom, stream);
 }
 
 extern "C" int vings_surfel_blend_backward_accumulate(int N, int H, int W, const uint32_t* ranges,
@@ -628,6 +665,14 @@ extern "C" int vings_surfel_blend_backward_accumulate(int N, int H, int W, const
                                            const float* final_T, const uint32_t* n_contrib,
                                            const float* dL_dcolor, const float* dL_dallmap,
                                            float* dgeom, void* stream) {
-    return blend_backward_impl(false, N, H, W, ranges, vals_sorted, geom, bg, pixel_mask, final_T,
-                               n_contrib, dL_dcolor, dL_dallmap, dgeom, stream);
+    return blend_backward_impl(false, false, N, H, W, ranges, vals_sorted, geom, bg, pixel_mask,
+                               final_T, n_contrib, dL_dcolor, dL_dallmap, dgeom, stream);
+}
+
+extern "C" int vings_surfel_blend_backward_accumulate_lean(
+    int N, int H, int W, const uint32_t* ranges, const uint32_t* vals_sorted, const float* geom,
+    const float* bg, const uint8_t* pixel_mask, const float* final_T, const uint32_t* n_contrib,
+    const float* dL_dcolor, const float* dL_dallmap, float* dgeom, void* stream) {
+    return blend_backward_impl(false, true, N, H, W, ranges, vals_sorted, geom, bg, pixel_mask,
+                               final_T, n_contrib, dL_dcolor, dL_dallmap, dgeom, stream);
 }

@@ -359,10 +359,12 @@ class SurfelMapper:
             # the projection applies the activations itself and fills fb["opac" / "scales" / "rot"]
             xyz, rgb = P["_xyz"].detach(), P["_rgb"].detach()
             dgeom = torch.empty((max(n, 1), surfel.GRAD_STRIDE), dtype=torch.float32, device=dev)
+            # (the loss has no term in the median depth or the flow: the lean blend passes)
+            lean = settings.u2_minus_u1 is None
             st, aux = surfel.rasterize_forward(
                 xyz, rgb, fb["opac"], fb["scales"], fb["rot"], settings,
                 raw=(P["_opacity"].detach(), P["_scaling"].detach(), P["_rotation"].detach()),
-                dgeom=dgeom)
+                dgeom=dgeom, lean=lean)
             single = reducer is None or reducer.world == 1
             compact = not single and reducer.compact
             if compact:
@@ -373,7 +375,7 @@ class SurfelMapper:
                                                          self.loss_weights, cache=True)
             g = fb["grads"]
             view, proj = aux[0], aux[1]
-            surfel.blend_backward(st, aux, d_rgb, d_allmap, dgeom=dgeom)
+            surfel.blend_backward(st, aux, d_rgb, d_allmap, dgeom=dgeom, lean=lean)
             if compact:
                 self._exchange_compact(L, reducer, st, xyz, fb, view, proj, dgeom, kf_id, stream)
             else:
@@ -425,7 +427,8 @@ class SurfelMapper:
                                                          self.loss_weights, cache=True)
             g = fb["grads"]
             view, proj = aux[0], aux[1]
-            surfel.blend_backward(st, aux, d_rgb, d_allmap, dgeom=dgeom)
+            surfel.blend_backward(st, aux, d_rgb, d_allmap, dgeom=dgeom,
+                                  lean=settings.u2_minus_u1 is None)
             count_ptr = st.tail_ptr + 8                    # third count word: D
             _lib.check(L.vings_surfel_project_backward_finish_guarded(
                 n, st.H, st.W, 1.0, ptr(xyz), ptr(fb["scales"]), ptr(fb["rot"]), ptr(view),

@@ -82,16 +82,20 @@ class thread_binning:
 
 
 def rasterize_forward(means3D, colors, opacities, scales, rotations, settings, keep_keys=False,
-                      raw=None, dgeom=None):
+                      raw=None, dgeom=None, lean=False):
     """Run projection -> binning -> blend. Returns (SurfelForwardState, aux).
 
     `raw` = (raw_opacity, raw_scaling, raw_rotation): the stored parameters.  The projection
     then applies the mapper's activations itself and FILLS opacities / scales / rotations
     (which only need to be allocated) instead of reading them.  With `raw`, `dgeom`
     ([N, GRAD_STRIDE] float32) may be handed over too: the projection zeroes the rows the
-    backward pass will add into, and `blend_backward(..., dgeom=dgeom)` skips its own clearing."""
+    backward pass will add into, and `blend_backward(..., dgeom=dgeom)` skips its own clearing.
+    `lean`: the blend pass of the mapper's own view step, which leaves the median depth and the
+    flow planes at zero (vings_surfel_blend_forward_lean)."""
+    if lean and settings.u2_minus_u1 is not None:
+        raise _lib.VingsError("the lean blend passes carry no flow")
     return _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys, True, raw,
-                    dgeom)
+                    dgeom, lean)
 
 
 def view_importance(means3D, colors, opacities, scales, rotations, settings, out=None,
@@ -119,7 +123,7 @@ _D_HINT = {}       # (device index, H, W) -> (instance count, depth key bits) of
 
 
 def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys, blend, raw=None,
-             dgeom=None):
+             dgeom=None, lean=False):
     L = _lib.lib()
     dev = means3D.device
     N = means3D.shape[0]
@@ -176,9 +180,9 @@ def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys,
         st.allmap = torch.empty((AUX_CHANNELS, H, W), dtype=torch.float32, device=dev)
         st.final_T = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         st.n_contrib = torch.empty((2, H, W), dtype=torch.int32, device=dev)
-        check(L.vings_surfel_blend_forward(H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom),
-                                           ptr(bg), ptr(mask), ptr(st.color), ptr(st.allmap),
-                                           ptr(st.final_T), ptr(st.n_contrib), stream),
+        fwd = L.vings_surfel_blend_forward_lean if lean else L.vings_surfel_blend_forward
+        check(fwd(H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg), ptr(mask),
+                  ptr(st.color), ptr(st.allmap), ptr(st.final_T), ptr(st.n_contrib), stream),
               "vings_surfel_blend_forward")
 
     # The instance count D comes back from the projection through the host.  Waiting for it
@@ -293,9 +297,10 @@ def rasterize_forward_fixed(means3D, colors, opacities, scales, rotations, setti
     st.allmap = torch.empty((AUX_CHANNELS, H, W), dtype=torch.float32, device=dev)
     st.final_T = torch.empty((3, H, W), dtype=torch.float32, device=dev)
     st.n_contrib = torch.empty((2, H, W), dtype=torch.int32, device=dev)
-    check(L.vings_surfel_blend_forward(H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg),
-                                       ptr(mask), ptr(st.color), ptr(st.allmap), ptr(st.final_T),
-                                       ptr(st.n_contrib), stream), "vings_surfel_blend_forward")
+    fwd = L.vings_surfel_blend_forward if flow is not None else L.vings_surfel_blend_forward_lean
+    check(fwd(H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg), ptr(mask), ptr(st.color),
+              ptr(st.allmap), ptr(st.final_T), ptr(st.n_contrib), stream),
+          "vings_surfel_blend_forward")
     st.D = None          # on the device / in count_words only
     st.keys = None
     st.tail_ptr = tail   # device address of the count words (for the guarded entry points)
@@ -303,7 +308,7 @@ def rasterize_forward_fixed(means3D, colors, opacities, scales, rotations, setti
     return st, (view, proj, bg, mask, flow)
 
 
-def blend_backward(st, aux, g_color, g_allmap, dgeom=None):
+def blend_backward(st, aux, g_color, g_allmap, dgeom=None, lean=False):
     """Pixel half of the backward pass: the per-splat accumulator rows dgeom [N, GRAD_STRIDE]
     that vings_surfel_project_backward (or its fused _finish form) turns into gradients.
     `dgeom`: rows already cleared by the forward pass (rasterize_forward(dgeom=...)); the pass
@@ -312,11 +317,14 @@ def blend_backward(st, aux, g_color, g_allmap, dgeom=None):
     _, _, bg, mask, _ = aux
     N, H, W = st.N, st.H, st.W
     dev = st.geom.device
+    if lean and dgeom is None:
+        raise _lib.VingsError("the lean backward pass adds into rows the forward pass cleared: pass dgeom")
     if dgeom is not None:
-        check(L.vings_surfel_blend_backward_accumulate(
-            N, H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg), ptr(mask),
-            ptr(st.final_T), ptr(st.n_contrib), ptr(g_color), ptr(g_allmap), ptr(dgeom),
-            stream_ptr(dev)), "vings_surfel_blend_backward_accumulate")
+        bwd = (L.vings_surfel_blend_backward_accumulate_lean if lean
+               else L.vings_surfel_blend_backward_accumulate)
+        check(bwd(N, H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg), ptr(mask),
+                  ptr(st.final_T), ptr(st.n_contrib), ptr(g_color), ptr(g_allmap), ptr(dgeom),
+                  stream_ptr(dev)), "vings_surfel_blend_backward_accumulate")
         return dgeom
     dgeom = torch.empty((max(N, 1), GRAD_STRIDE), dtype=torch.float32, device=dev)
     check(L.vings_surfel_blend_backward(
