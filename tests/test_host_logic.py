@@ -50,6 +50,23 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert rc == -1
     with pytest.raises(_lib.VingsError):
         _lib.check(rc, "vings_sparse_adam")
+    # the exchange, capture and cache entry points check their arguments before any launch too
+    assert L.vings_splat_touched(-1, None, None, None) == -1
+    assert L.vings_splat_touched(0, None, None, None) == 0
+    assert L.vings_splat_touched(5, None, None, None) == -1
+    assert L.vings_splat_exchange_step(0, 256, None, None, None, None, None, None, 0.9, 0.999, 1e-15,
+                                       None, None, None, None) == 0
+    assert L.vings_splat_exchange_step(300, 256, None, None, None, None, None, None, 0.9, 0.999, 1e-15,
+                                       None, None, None, None) == -1
+    assert b"chunk" in L.vings_last_error()
+    assert L.vings_splat_compact_plan_device(7, None, None, None, 0, None, None) == -1
+    assert L.vings_surfel_project_backward_pack(4, 8, 8, 1.0, *([None] * 10), 0, *([None] * 5), 0, None) == -1
+    assert L.vings_surfel_project_enqueue_activate(4, 8, 8, 1.0, *([None] * 20)) == -1
+    assert L.vings_sparse_adam_multi_guarded(1, *([None] * 7), 0.9, 0.999, 1e-15, 4, None, 10, None) == -1
+    assert L.vings_mapping_loss_cached(8, 8, *([None] * 5), None, 1.0, 1.0, 0.0, 0.0, None,
+                                       *([None] * 4), 0, None, 0, None) == -1
+    assert L.vings_mapping_loss_gt_cache_bytes(1080, 1920) == 1080 * 1920 * 25 + 256
+    assert L.vings_splat_exchange_columns() == 14
 
 
 def test_cpu_tensors_are_rejected():
