@@ -20,9 +20,8 @@
 // Backward walks the same bits back to front.  Per splat the 20 partial
 // gradients of the contributing pixels are summed over the wave with a
 // transposing tree (cross-half exchange through the LDS crossbar, row pairs
-// with v_permlane16_swap, DPP inside a row), the four waves meet in an LDS
-// accumulator for the batch, and each batch is flushed with one global float
-// atomic per (splat, component).
+// with v_permlane16_swap, DPP inside a row) and added to the splat's gradient
+// row with one coalesced 80-byte global float atomic per (wave, splat) pair.
 //
 // Serves GaussianRasterizer.forward / backward as called at
 // /root/reference/scripts/gaussian/gaussian_base.py:193-203,382 and consumed
@@ -39,10 +38,9 @@ constexpr float kAlphaMax = 0.99f;
 constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kTMin = 0.0001f;
 constexpr int kBatch = 256;
-// backward batch: 160 records keep the kernel at 26.4 KB of LDS, i.e. six workgroups per CU
-// (160 KB) instead of three with 256; its launch bound asks for 6 waves per SIMD (80 VGPRs:
-// the staging code spills a little, the blend loop does not)
-constexpr int kBatchBwd = 160;
+// backward batch: 21.5 KB of LDS for the staged records; the launch bound asks for 6 waves per
+// SIMD (80 VGPRs: the staging code spills a little, the blend loop does not)
+constexpr int kBatchBwd = 256;
 constexpr int kRec4 = VINGS_GEOM_STRIDE / 4;  // float4 per record
 constexpr int kGrad = VINGS_GRAD_STRIDE;      // gradient components per splat
 
@@ -363,7 +361,6 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_dallmap, float* __restrict__ dgeom) {
     __shared__ float4 rec[kBatchBwd * (kRec4 - 1)];
-    __shared__ float acc[kBatchBwd * kGrad];
     __shared__ uint32_t ids[kBatchBwd];
     __shared__ unsigned long long hit[16];
     __shared__ uint32_t wmax[4];
@@ -376,6 +373,18 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
     const size_t HW = (size_t)H * W;
     const size_t pix = (size_t)py * W + px;
     const bool active = inside && !(pixel_mask && pixel_mask[pix] == 0);
+    // Lane t < 20 adds component t of every (wave, splat) pair straight to the splat's row in
+    // global memory: one 80-byte coalesced float atomic per pair.  (An LDS accumulator shared by
+    // the four waves and flushed once per batch halves the global atomics, but its LDS float
+    // atomics, five instructions per pair, cost more than that saves: 1.30 -> 1.275 ms without
+    // it, and its 12.8 KB of LDS now hold a batch of 256 records instead of 160.)  Component
+    // t = 4k + c sits, after the row sums, in register k of the row whose comp0 is c; lane
+    // 16 row + k of that row presents it, and lane t fetches it from there.
+    const int lane_ = threadIdx.x & 63;
+    const int present = lane_ & 15;                                   // register this lane presents
+    const int fetch_row = (((lane_ & 3) & 1) << 1) | ((lane_ & 3) >> 1);
+    const int fetch_from = ((fetch_row << 4) | (lane_ >> 2)) << 2;     // byte address for ds_bpermute
+    const float flush_sign = lane_ < 6 ? -1.f : 1.f;
     const float fx = (float)px, fy = (float)py;
     const uint32_t r0 = ranges[2 * tile];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -428,7 +437,6 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
         __syncthreads();  // previous batch fully flushed
         stage_batch(rec, hit, geom, vals, r0 + bstart + threadIdx.x, r0 + bstart + cnt, ids,
                     (float)(tx * 16), (float)(ty * 16));
-        for (int k = threadIdx.x; k < cnt * kGrad; k += 256) acc[k] = 0.f;
         __syncthreads();
         // the four ballot words of this wave's block, back to front (plain nested loops: see
         // blend_fwd_kernel)
@@ -536,25 +544,18 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
                 for (int k = 0; k < kGrad / 4; ++k)
                     u5[k] = half_row_sum(swap16_add(v10[2 * k], v10[2 * k + 1]));
                 row_mirror_add5(u5[0], u5[1], u5[2], u5[3], u5[4]);
-                const int row = lane >> 4;
-                const int comp0 = ((row & 1) << 1) | (row >> 1);
-                // unconditional: testing each sum for zero costs more than adding one
-                if ((lane & 15) == 0) {
-#pragma unroll
-                    for (int k = 0; k < kGrad / 4; ++k)
-                        atomicAdd(&acc[j * kGrad + 4 * k + comp0], u5[k]);
-                }
+                float v = u5[0];
+                v = present == 1 ? u5[1] : v;
+                v = present == 2 ? u5[2] : v;
+                v = present == 3 ? u5[3] : v;
+                v = present == 4 ? u5[4] : v;
+                const float mine = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(
+                    fetch_from, __builtin_bit_cast(int, v)));
+                // (dL/dTu = -dk and dL/dTv = -dl: the sign of components 0..5)
+                if (lane < kGrad)
+                    atomicAdd(&dgeom[(size_t)ids[j] * kGrad + lane], mine * flush_sign);
             }
           }
-        }
-        __syncthreads();
-        // flush: consecutive lanes write consecutive floats of the accumulator
-        for (int k = threadIdx.x; k < cnt * kGrad; k += 256) {
-            const float v = acc[k];
-            if (v != 0.f) {
-                const int jj = k / kGrad, c = k - jj * kGrad;
-                atomicAdd(&dgeom[(size_t)ids[jj] * kGrad + c], c < 6 ? -v : v);
-            }
         }
     }
 }
