@@ -30,8 +30,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=("auto", "c3", "c4", "c5"), default="auto",
                     help="BASELINE config: c3 = 8-keyframe window + DBA on every GPU (the one the "
                          "metric is quoted on); c4 = one 32-keyframe window whose keyframes are "
