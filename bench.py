@@ -326,7 +326,11 @@ def main():
                         "launch stream); traffic is NOT: it is the FETCH_SIZE / WRITE_SIZE "
                         "figure of the committed rocprofv3 PMC passes of this same workload "
                         "(profiles/, null for any other workload).  The kernel is bound by "
-                        "vector-instruction issue, not by HBM (profiles/*/blend_sq_counters.txt)"}
+                        "vector-instruction issue, not by HBM (profiles/*/blend_sq_counters.txt); "
+                        "more than half of the traffic is its write side, one 80-byte float atomic "
+                        "per (8x8 pixel block, splat) pair where the algorithmic count has one "
+                        "84-byte row per visible splat (an LDS accumulator per tile halves it and "
+                        "was measured slower)"}
     stage_ms = {k: round(v["ms"] / max(v["count"], 1), 4) for k, v in prof_all.items()}
     if loop is not None:
         ev = loop["events"]
