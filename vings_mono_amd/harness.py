@@ -403,6 +403,7 @@ class SurfelMapper:
         self.last_loss = loss_vec[0]
         self.last_loss_terms = loss_vec
         self._last_radii = st.radii
+        self._last_instances = int(st.D)
         return loss_vec
 
     # ------------------------------------------------------------------ view step as a HIP graph
@@ -440,6 +441,12 @@ class SurfelMapper:
                 "vings_surfel_project_backward_finish_guarded")
             self.optimizer.step(fb["vis"], n, guard=(count_ptr, capacity))
         return loss_vec, st
+
+    def drop_view_graphs(self):
+        """Forget the captured view steps (and give their memory pool back): the arrays they
+        address are about to be replaced."""
+        self.__dict__.pop("_view_graphs", None)
+        self.__dict__.pop("_view_graph_pool", None)
 
     def _graph_signature(self, settings, gt):
         """Everything a captured view step has baked in by address: a change (map maintenance
@@ -480,11 +487,10 @@ class SurfelMapper:
             # (a retired graph is kept until its successor is captured: the graphs of a mapper
             # share one memory pool, which must not lose its last user in between)
             retired, ent = ent.get("graph") or ent.get("retired"), None
-        from . import surfel
         if ent is None:
             loss_vec = self.fused_view(settings, intr, gt, Rw2c_host, kf_id)
             graphs[key] = {"sig": self._graph_signature(settings, gt), "graph": None,
-                           "retired": retired, "D": int(surfel.LAST_INSTANCE_COUNT)}
+                           "retired": retired, "D": self._last_instances}
             return loss_vec
         if ent["graph"] is not None:
             # the replay of one window ago has long finished; its count tells whether it fit
@@ -493,7 +499,7 @@ class SurfelMapper:
             if d_prev > ent["capacity"]:
                 self.fused_view(settings, intr, gt, Rw2c_host, kf_id)     # the dropped step
                 ent["retired"], ent["graph"] = ent["graph"], None
-                ent["D"] = int(surfel.LAST_INSTANCE_COUNT)
+                ent["D"] = self._last_instances
                 ent["sig"] = self._graph_signature(settings, gt)
             elif d_prev > 0.97 * ent["capacity"]:
                 ent["retired"], ent["graph"] = ent["graph"], None         # growing: more room

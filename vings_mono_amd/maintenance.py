@@ -92,6 +92,7 @@ def prune(mapper, prune_mask):
         mapper._pending_keys = new[("pending", "keys")]
     mapper.n = m
     mapper._fb = None          # buffers of the fused view step are sized per splat count
+    mapper.drop_view_graphs()  # ... and so is everything a captured view step has baked in
     return m
 
 
@@ -280,6 +281,7 @@ def add_splats(mapper, new_params):
         mapper._pending_keys = torch.cat((mapper._pending_keys, z(k, 2, dt=torch.int64)))
     mapper.n += k
     mapper._fb = None
+    mapper.drop_view_graphs()
     return mapper.n
 
 
