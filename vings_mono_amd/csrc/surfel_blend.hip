@@ -338,21 +338,6 @@ __global__ __launch_bounds__(256, 6) void blend_importance_kernel(
 // backward
 // ---------------------------------------------------------------------------
 
-// Last step of the sum over the 16 lanes of a DPP row, for five registers at once, written
-// as fused v_add_f32_dpp: left to the compiler it is sunk into the lane-0-only atomic region
-// as v_mov 0 + v_mov_dpp + v_add (three issues each).  The s_nop covers the two wait states
-// a DPP read needs after a VALU write of its source.
-__device__ __forceinline__ void row_mirror_add5(float& a, float& b, float& c, float& d, float& e) {
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1"
-        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
-}
-
 template <bool kLean>   // kLean: dL/dallmap[5], [7], [8] are zero and not read (see blend_fwd_kernel)
 __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
     int H, int W, int gx, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ vals,
@@ -381,10 +366,13 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
     // t = 4k + c sits, after the row sums, in register k of the row whose comp0 is c; lane
     // 16 row + k of that row presents it, and lane t fetches it from there.
     const int lane_ = threadIdx.x & 63;
-    const int present = lane_ & 15;                                   // register this lane presents
     const int fetch_row = (((lane_ & 3) & 1) << 1) | ((lane_ & 3) >> 1);
-    const int fetch_from = ((fetch_row << 4) | (lane_ >> 2)) << 2;     // byte address for ds_bpermute
+    // lane of a row that ends up with register k of the row sums (see the reduction below)
+    const int pos_of_k = (lane_ >> 2) == 0 ? 0 : (lane_ >> 2) == 1 ? 8 : (lane_ >> 2) == 2 ? 4
+                         : (lane_ >> 2) == 3 ? 12 : 2;
+    const int fetch_from = ((fetch_row << 4) | pos_of_k) << 2;         // byte address for ds_bpermute
     const float flush_sign = lane_ < 6 ? -1.f : 1.f;
+    const bool low8 = (lane_ & 8) == 0, low4 = (lane_ & 4) == 0, low2 = (lane_ & 2) == 0;
     const float fx = (float)px, fy = (float)py;
     const uint32_t r0 = ranges[2 * tile];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -519,7 +507,7 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
                 // add) does the same for odd/even 16-lane rows.  After the two steps 20
                 // components have become 5 registers whose four rows hold different components
                 // (row r, register k -> component 4k + {0,2,1,3}[r]), each already summed over
-                // the four rows; a DPP row sum finishes them.
+                // the four rows; step 3 sums inside the rows.
                 // Step 1 goes through ds_bpermute: the LDS crossbar is idle here, while
                 // v_permlane32_swap occupies the vector issue port for 10-12 cycles; the ten
                 // exchanges are independent, so their latency overlaps.  (Step 2 through
@@ -541,14 +529,20 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
                 }
                 float u5[kGrad / 4];
 #pragma unroll
-                for (int k = 0; k < kGrad / 4; ++k)
-                    u5[k] = half_row_sum(swap16_add(v10[2 * k], v10[2 * k + 1]));
-                row_mirror_add5(u5[0], u5[1], u5[2], u5[3], u5[4]);
-                float v = u5[0];
-                v = present == 1 ? u5[1] : v;
-                v = present == 2 ? u5[2] : v;
-                v = present == 3 ? u5[3] : v;
-                v = present == 4 ? u5[4] : v;
+                for (int k = 0; k < kGrad / 4; ++k) u5[k] = swap16_add(v10[2 * k], v10[2 * k + 1]);
+                // Step 3, inside a 16-lane row, keeps transposing: every level halves the
+                // distance AND the number of registers (a pair of registers meets in one whose
+                // lane groups own different components), 15 instructions where summing the five
+                // registers separately takes 20.  Levels: row_mirror (8), row_half_mirror (4),
+                // quad_perm 2301 (2), quad_perm 1032 (1).  The row sums of registers 0..4 end in
+                // lanes 0, 8, 4, 12 and 2 of the row.
+                const float r01 = (low8 ? u5[0] : u5[1]) + dpp_f<0x140>(low8 ? u5[1] : u5[0]);
+                const float r23 = (low8 ? u5[2] : u5[3]) + dpp_f<0x140>(low8 ? u5[3] : u5[2]);
+                const float r4 = u5[4] + dpp_f<0x140>(u5[4]);
+                const float s03 = (low4 ? r01 : r23) + dpp_f<0x141>(low4 ? r23 : r01);
+                const float s4 = r4 + dpp_f<0x141>(r4);
+                const float z = (low2 ? s03 : s4) + dpp_f<0x4E>(low2 ? s4 : s03);
+                const float v = z + dpp_f<0xB1>(z);
                 const float mine = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(
                     fetch_from, __builtin_bit_cast(int, v)));
                 // (dL/dTu = -dk and dL/dTv = -dl: the sign of components 0..5)
