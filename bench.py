@@ -59,6 +59,10 @@ def parse():
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="all ranks share GPU 0 and exchange over gloo: checks the multi-rank "
                          "path on a one-GPU box; the figure printed is not a benchmark result")
+    ap.add_argument("--rehearse-rccl", action="store_true",
+                    help="one rank, one GPU, a one-rank RCCL communicator, the multi-GPU view step "
+                         "with every collective issued (each is the identity): what the exchange "
+                         "costs before any byte crosses a link; not a benchmark result")
     ap.add_argument("--exchange", choices=("compact", "planar"), default="compact",
                     help="N > 1: compact = only the rows some rank touched travel, in chunks "
                          "applied while the next one is reduced; planar = all rows in one all-reduce")
@@ -106,13 +110,27 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); there is no CPU path")
+    if args.rehearse_rccl:
+        assert world == 1, "--rehearse-rccl is the one-rank form: start it without a launcher"
     if args.rehearse_gloo:
         local_rank = 0
         import faulthandler
         faulthandler.dump_traceback_later(90, exit=True)       # a stuck rehearsal names its line
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    json_out = sys.stdout
+    if world > 1 or args.rehearse_rccl:
+        # RCCL prints a version banner on stdout when its communicator comes up; stdout is for
+        # the one JSON line, so everything else of this process goes to stderr
+        sys.stdout.flush()
+        json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    if args.rehearse_rccl:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    elif world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.rehearse_gloo:
@@ -180,7 +198,9 @@ def main():
             gts.append({"rgb": pred["rgb"].clone(), "depth": depth,
                         "depth_cov": torch.ones_like(depth)})
     del gt_mapper_params
-    reducer = parallel.GradReducer(mapper.n, dev, world, n_chunks=args.exchange_chunks,
+    # (the one-rank RCCL rehearsal tells the reducer of two ranks so that the exchange runs)
+    reducer = parallel.GradReducer(mapper.n, dev, 2 if args.rehearse_rccl else world,
+                                   n_chunks=args.exchange_chunks,
                                    compact=args.exchange == "compact")
     if loop is not None:
         from vings_mono_amd import maintenance
@@ -296,6 +316,8 @@ def main():
         return round(n_views_total * n_steps / (time.perf_counter() - t), 3)
 
     reference_api = reference_binning = graph_replay = None
+    if args.rehearse_rccl:
+        args.no_side_runs = True
     if world == 1 and not args.no_side_runs and not args.no_graph_run and loop is None \
             and not (args.autograd or args.torch_loss):
         step(graphed=True)          # eager: learns the instance counts
@@ -352,7 +374,8 @@ def main():
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic" + (" (gloo rehearsal on one GPU: not a benchmark result)" if args.rehearse_gloo else ""),
+            "data": "synthetic" + (" (gloo rehearsal on one GPU: not a benchmark result)" if args.rehearse_gloo else "")
+                    + (" (one-rank RCCL rehearsal of the multi-GPU step: not a benchmark result)" if args.rehearse_rccl else ""),
             "config": {"workload": ("BASELINE config %s: %.1fM splats, %s %dx%d%s" % (
                                         workload[1], args.splats / 1e6,
                                         ("%d-keyframe window per GPU" % V) if workload == "c3" else
@@ -368,7 +391,7 @@ def main():
                        "dba": None if dba is None else dict(dba.describe(), stream=args.dba_stream),
                        "instances_D": stats["D"], "visible": stats["n_vis"],
                        "parallelism": f"views sharded over {world} GPU(s), grad all-reduce",
-                       "exchange": None if world == 1 else (
+                       "exchange": None if reducer.world == 1 else (
                            {"form": "planar", "rows": mapper.n} if reducer.last_exchanged_rows is None
                            else {"form": "compact", "chunks": args.exchange_chunks,
                                  "rows": reducer.last_exchanged_rows, "of": mapper.n})},
@@ -388,8 +411,8 @@ def main():
                 "what": "fused step with the reference's 3-sigma tile squares (bit-exact instance list)"},
             "loss": None if mapper.last_loss is None else round(float(mapper.last_loss), 6),
         }
-        print(json.dumps(out))
-    if world > 1:
+        print(json.dumps(out), file=json_out, flush=True)
+    if world > 1 or args.rehearse_rccl:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -76,3 +76,30 @@ def test_multi_rank_view_steps(tmp_path, world):
     for k in ("global_scores", "local_scores", "kf_max"):
         scale = float(s0["autograd"][k].abs().max())
         assert float((s0["autograd"][k] - s0["fused"][k]).abs().max()) <= 1e-4 * scale, k
+
+
+def test_exchange_over_rccl_one_rank(tmp_path):
+    """The exchange with its collectives issued through RCCL (backend "nccl") on a one-rank
+    communicator — all this box can host: the sums are over one rank, so the step must equal
+    the single-GPU step (to what two runs of the float-atomic backward differ by), and the
+    record maxima must come back unchanged through the int64 MAX."""
+    out = str(tmp_path / "rccl.pt")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OMP_NUM_THREADS="2")
+    res = subprocess.run([sys.executable, os.path.join(HERE, "_rccl_worker.py"), out], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    s = torch.load(out, weights_only=True)
+    assert s["backend"] == "nccl"
+    assert all(0 < m < 5000 for m in s["exchanged_rows"]), s["exchanged_rows"]
+    names = ("_xyz", "_rgb", "_opacity", "_scaling", "_rotation")
+    for impl in ("autograd", "fused", "fused_planar"):
+        for k in names:
+            us = s["single"][k] - s["raw"][k]
+            ui = s[impl][k] - s["raw"][k]
+            scale = float(us.abs().max())
+            assert scale > 0, k
+            assert float((us - ui).abs().max()) <= 2e-2 * scale, (impl, k)
+        for k in ("global_scores", "local_scores", "kf_max"):
+            scale = float(s["single"][k].abs().max())
+            assert float((s["single"][k] - s[impl][k]).abs().max()) <= 1e-4 * scale, (impl, k)
+        assert float((s["single"]["kf_id"] == s[impl]["kf_id"]).float().mean()) >= 0.999, impl
