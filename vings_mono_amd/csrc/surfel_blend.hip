@@ -362,14 +362,18 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
     // global memory: one 80-byte coalesced float atomic per pair.  (An LDS accumulator shared by
     // the four waves and flushed once per batch halves the global atomics, but its LDS float
     // atomics, five instructions per pair, cost more than that saves: 1.30 -> 1.275 ms without
-    // it, and its 12.8 KB of LDS now hold a batch of 256 records instead of 160.)  Component
-    // t = 4k + c sits, after the row sums, in register k of the row whose comp0 is c; lane
-    // 16 row + k of that row presents it, and lane t fetches it from there.
+    // it, and its 12.8 KB of LDS now hold a batch of 256 records instead of 160.)  Slot
+    // 4k + c of the reduction sits, after the row sums, in register k of the row whose first
+    // slot is c; one lane of that row presents it, and the lane whose component lives in that
+    // slot fetches it from there.
     const int lane_ = threadIdx.x & 63;
-    const int fetch_row = (((lane_ & 3) & 1) << 1) | ((lane_ & 3) >> 1);
+    // (components 11 and 14 trade places inside the reduction, so that 11 pairs with 15: both
+    // are the blend weight times a per-pixel constant, see keep14 below)
+    const int slot_ = lane_ == 11 ? 14 : lane_ == 14 ? 11 : lane_;
+    const int fetch_row = (((slot_ & 3) & 1) << 1) | ((slot_ & 3) >> 1);
     // lane of a row that ends up with register k of the row sums (see the reduction below)
-    const int pos_of_k = (lane_ >> 2) == 0 ? 0 : (lane_ >> 2) == 1 ? 8 : (lane_ >> 2) == 2 ? 4
-                         : (lane_ >> 2) == 3 ? 12 : 2;
+    const int pos_of_k = (slot_ >> 2) == 0 ? 0 : (slot_ >> 2) == 1 ? 8 : (slot_ >> 2) == 2 ? 4
+                         : (slot_ >> 2) == 3 ? 12 : 2;
     const int fetch_from = ((fetch_row << 4) | pos_of_k) << 2;         // byte address for ds_bpermute
     const float flush_sign = lane_ < 6 ? -1.f : 1.f;
     const bool low8 = (lane_ & 8) == 0, low4 = (lane_ & 4) == 0, low2 = (lane_ & 2) == 0;
@@ -407,6 +411,15 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
     const float A_final = 1.f - T_final;
     const float bg_dot = bg[0] * gC0 + bg[1] * gC1 + bg[2] * gC2;
     const float gabs = fabsf(gC0) + fabsf(gC1) + fabsf(gC2);
+    // Components 11/15, 12/13, 16/17 and 18/19 are the blend weight times a per-pixel constant,
+    // and the first reduction step hands one of each pair to the other half of the wave: which
+    // constant a lane keeps and which it sends is decided here, once, instead of by two selects
+    // per pair and splat.
+    const bool lo_half = (threadIdx.x & 32) == 0;
+    const float keep14 = lo_half ? gN0 : gC0, send14 = lo_half ? gC0 : gN0;
+    const float keep12 = lo_half ? gN1 : gN2, send12 = lo_half ? gN2 : gN1;
+    const float keep16 = lo_half ? gC1 : gC2, send16 = lo_half ? gC2 : gC1;
+    const float keep18 = lo_half ? 1.f : gabs, send18 = lo_half ? gabs : 1.f;
     const float c1 = kFarN / (kFarN - kNearN);
     const float c2 = (kFarN * kNearN) / (kFarN - kNearN);
 
@@ -474,11 +487,8 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
             float dL_dz = 2.f * w * (m * A_final - M1f) * gDist * dm_dd + w * gD;
             if (!kLean) dL_dz += (c & (pos + 1 == medc)) ? gMed : 0.f;
             float g[kGrad];
-            g[11] = w * gN0; g[12] = w * gN1; g[13] = w * gN2;
-            g[14] = G * dL_dalpha;
-            g[15] = w * gC0; g[16] = w * gC1; g[17] = w * gC2;
-            g[18] = w;
-            g[19] = w * gabs;
+            g[11] = G * dL_dalpha;     // component 14 (slot 11)
+            // (slots 12..19: formed in the reduction from the constants chosen above)
             const float a = -(s.opa * dL_dalpha) * G;  // dL/drho * -2, zero for idle lanes
             const float sx = c3 ? h.sx : 0.f, sy = c3 ? h.sy : 0.f, rz = c3 ? h.rz : 0.f;
             const float dsx = a * sx + dL_dz * s.Tw[0];
@@ -506,7 +516,7 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
                 // will own and fetches the partner's share of it.  Step 2 (v_permlane16_swap +
                 // add) does the same for odd/even 16-lane rows.  After the two steps 20
                 // components have become 5 registers whose four rows hold different components
-                // (row r, register k -> component 4k + {0,2,1,3}[r]), each already summed over
+                // (row r, register k -> slot 4k + {0,2,1,3}[r]), each already summed over
                 // the four rows; step 3 sums inside the rows.
                 // Step 1 goes through ds_bpermute: the LDS crossbar is idle here, while
                 // v_permlane32_swap occupies the vector issue port for 10-12 cycles; the ten
@@ -520,9 +530,14 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
                     float mine[kGrad / 2], theirs[kGrad / 2];
 #pragma unroll
                     for (int i = 0; i < kGrad / 2; ++i) {
-                        mine[i] = lo ? g[2 * i] : g[2 * i + 1];
+                        float send;
+                        if (i == 7) { mine[i] = w * keep14; send = w * send14; }
+                        else if (i == 6) { mine[i] = w * keep12; send = w * send12; }
+                        else if (i == 8) { mine[i] = w * keep16; send = w * send16; }
+                        else if (i == 9) { mine[i] = w * keep18; send = w * send18; }
+                        else { mine[i] = lo ? g[2 * i] : g[2 * i + 1]; send = lo ? g[2 * i + 1] : g[2 * i]; }
                         theirs[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(
-                            partner, __builtin_bit_cast(int, lo ? g[2 * i + 1] : g[2 * i])));
+                            partner, __builtin_bit_cast(int, send)));
                     }
 #pragma unroll
                     for (int i = 0; i < kGrad / 2; ++i) v10[i] = mine[i] + theirs[i];
