@@ -551,10 +551,21 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
                 // registers separately takes 20.  Levels: row_mirror (8), row_half_mirror (4),
                 // quad_perm 2301 (2), quad_perm 1032 (1).  The row sums of registers 0..4 end in
                 // lanes 0, 8, 4, 12 and 2 of the row.
-                const float r01 = (low8 ? u5[0] : u5[1]) + dpp_f<0x140>(low8 ? u5[1] : u5[0]);
-                const float r23 = (low8 ? u5[2] : u5[3]) + dpp_f<0x140>(low8 ? u5[3] : u5[2]);
+                float r01, r23, s03;
+                // (the lanes of banks 2, 3 = the high half of a row take the second register:
+                // a bank mask on the second add instead of two selects)
+                asm volatile("s_nop 1\n\t"
+                             "v_add_f32_dpp %0, %3, %3 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                             "v_add_f32_dpp %1, %5, %5 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                             "v_add_f32_dpp %0, %4, %4 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+                             "v_add_f32_dpp %1, %6, %6 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+                             "s_nop 1\n\t"
+                             "v_add_f32_dpp %2, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                             "s_nop 0\n\t"
+                             "v_add_f32_dpp %2, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa"
+                             : "=&v"(r01), "=&v"(r23), "=&v"(s03)
+                             : "v"(u5[0]), "v"(u5[1]), "v"(u5[2]), "v"(u5[3]));
                 const float r4 = u5[4] + dpp_f<0x140>(u5[4]);
-                const float s03 = (low4 ? r01 : r23) + dpp_f<0x141>(low4 ? r23 : r01);
                 const float s4 = r4 + dpp_f<0x141>(r4);
                 const float z = (low2 ? s03 : s4) + dpp_f<0x4E>(low2 ? s4 : s03);
                 const float v = z + dpp_f<0xB1>(z);
