@@ -96,10 +96,11 @@ __device__ __forceinline__ bool eval_hit(const Splat& s, float fx, float fy, Hit
     h.rho2d = kFilterInvSq * (h.dx * h.dx + h.dy * h.dy);
     const float rho = fminf(h.rho3d, h.rho2d);
     h.depth = (h.rho3d <= h.rho2d) ? (h.sx * s.Tw[0] + h.sy * s.Tw[1]) + s.Tw[2] : s.Tw[2];
-    const float power = -0.5f * rho;
-    h.G = __expf(power);
+    // G = exp(-rho / 2) as one multiply and v_exp_f32: __expf(-0.5f * rho) is exp2 of
+    // (-0.5f * rho) * log2(e), and halving is exact, so rho * (-log2(e) / 2) has the same bits
+    h.G = __builtin_amdgcn_exp2f(rho * __uint_as_float(0xbf38aa3bu));
     h.alpha = fminf(kAlphaMax, s.opa * h.G);
-    return (h.pz != 0.f) & !(h.depth < kNearN) & !(power > 0.f) & (h.alpha >= kAlphaMin);
+    return (h.pz != 0.f) & !(h.depth < kNearN) & !(rho < 0.f) & (h.alpha >= kAlphaMin);
 }
 
 // Gather this lane's record of the batch into LDS and publish, per 8x8 block of the
