@@ -287,6 +287,12 @@ ALT_CASES = [
     dict(B=2, S=1, H=135, W=240, H2=135, W2=240, C=128, r=3),    # 1080p / 8: no volume possible
     dict(B=2, S=1, H=9, W=35, H2=7, W2=11, C=12, r=2),           # ragged chunk, small channels
     dict(B=1, S=1, H=5, W=6, H2=5, W2=6, C=4, r=4),              # window larger than a wave
+    # smooth flow fields (what a tracker feeds): neighbouring windows overlap and the workgroup
+    # stages their bounding rectangle through LDS; ragged pixel blocks, borders, S = 2
+    dict(B=3, S=2, H=43, W=77, H2=43, W2=77, C=128, r=3, smooth=1.0),
+    dict(B=2, S=1, H=135, W=240, H2=67, W2=120, C=128, r=3, smooth=0.5),
+    dict(B=2, S=1, H=30, W=50, H2=30, W2=50, C=32, r=2, smooth=2.0),
+    dict(B=2, S=1, H=18, W=21, H2=18, W2=21, C=16, r=0, smooth=0.3),
 ]
 
 
@@ -297,6 +303,14 @@ def _alt_inputs(c, seed=3):
     # targets scattered over fmap2 and a margin outside it (zero padding), a few far away
     x = rng.uniform(-5, c["W2"] + 4, size=(c["B"], c["S"], c["H"], c["W"]))
     y = rng.uniform(-5, c["H2"] + 4, size=(c["B"], c["S"], c["H"], c["W"]))
+    if c.get("smooth"):
+        # pixel grid scaled onto fmap2 + a per-(b, s) translation and shear that pushes part of
+        # the field across the border + per-pixel jitter
+        gy, gx = np.meshgrid(np.arange(c["H"]), np.arange(c["W"]), indexing="ij")
+        sh = rng.uniform(-6, 6, size=(c["B"], c["S"], 2, 1, 1))
+        x = gx * (c["W2"] / c["W"]) + sh[:, :, 0] + 0.03 * gy + rng.normal(size=x.shape) * c["smooth"]
+        y = gy * (c["H2"] / c["H"]) + sh[:, :, 1] - 0.02 * gx + rng.normal(size=y.shape) * c["smooth"]
+        x[-1, -1, 2, 3] = -3e6; y[-1, -1, 1, 1] = c["H2"] + 40.0   # one stray target in a block
     x[0, 0, 0, 0] = 1e7; y[0, 0, 0, 1] = -1e7
     return f1, f2, np.stack([x, y], -1).astype(np.float32)
 
@@ -314,7 +328,7 @@ def test_altcorr_forward_parity(case):
     np.testing.assert_allclose(got.cpu().numpy(), want, atol=1e-5 * np.abs(want).max() + 1e-6)
 
 
-@pytest.mark.parametrize("case", ALT_CASES[:2] + ALT_CASES[3:])
+@pytest.mark.parametrize("case", ALT_CASES[:2] + ALT_CASES[3:5])
 def test_altcorr_backward_parity(case):
     from vings_mono_amd import dba
     dev = torch.device("cuda:0")

@@ -301,6 +301,176 @@ __global__ __launch_bounds__(256) void altcorr_fwd_kernel(
     }
 }
 
+// Tiled form (r <= 3, C a multiple of 16): a workgroup takes a 16x4 block of query pixels of one
+// (b, s), a wave one row of it, a lane one integer position of the (2r+2)^2 neighbourhood, for
+// all 16 pixels of the row at once (16 accumulators).  The targets of neighbouring pixels land
+// close to each other (a tracker's flow field is smooth), so their neighbourhoods overlap: the
+// workgroup takes the bounding rectangle of all of them inside fmap2 and, when it holds at most
+// kAltCap positions, passes it through LDS in chunks of 16 channels -- every fmap2 row is then
+// fetched once per workgroup with full-line loads instead of once per pixel by a lane of its
+// own.  Scattered targets (rectangle too large) read the rows from global memory as before.
+constexpr int kAltTW = 16, kAltTH = 4, kAltTile = kAltTW * kAltTH;
+constexpr int kAltCap = 512;      // fmap2 positions a workgroup stages
+constexpr int kAltCh = 16;        // channels per staged chunk
+constexpr int kAltStride = 20;    // floats per staged position: 16 + 4 (16-byte aligned, and the
+                                  // lanes of a 16-lane group fall into different banks)
+constexpr int kAltStageIters = kAltCap * (kAltCh / 4) / 256;
+constexpr size_t kAltTileLds =
+    sizeof(float) * (kAltCap * kAltStride + kAltTile * kAltCh + 4 * 64 + 4 * kAltTile + 4);
+
+template <bool kStaged>
+__device__ __forceinline__ void altcorr_row_dots(float (&acc)[kAltTW], const int (&off)[kAltTW],
+                                                 const float* __restrict__ f1row,
+                                                 const float* __restrict__ src) {
+#pragma unroll
+    for (int p = 0; p < kAltTW; ++p) {
+        const int o = off[p];
+        const float4* a4 = reinterpret_cast<const float4*>(f1row + p * kAltCh);
+        const float4* u4 = reinterpret_cast<const float4*>(src + (o < 0 ? 0 : o));
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < kAltCh / 4; ++c) {
+            const float4 u = u4[c], v = a4[c];
+            d += u.x * v.x; d += u.y * v.y; d += u.z * v.z; d += u.w * v.w;
+        }
+        acc[p] += o < 0 ? 0.f : d;
+    }
+}
+
+__global__ __launch_bounds__(256) void altcorr_fwd_tile_kernel(
+    const float* __restrict__ fmap1, const float* __restrict__ fmap2,
+    const float* __restrict__ coords, float* __restrict__ corr, int B, int S, int H, int W, int H2,
+    int W2, int C, int r) {
+    extern __shared__ float alt_lds[];
+    float* reg = alt_lds;                                  // [kAltCap][kAltStride]; at the end [K][64]
+    float* f1s = reg + kAltCap * kAltStride;               // [64 pixels][16 channels]
+    float* dots = f1s + kAltTile * kAltCh;                 // [4 waves][64]
+    int* ix0 = reinterpret_cast<int*>(dots + 4 * 64);      // [64] window origin of every pixel
+    int* iy0 = ix0 + kAltTile;
+    float* fdx = reinterpret_cast<float*>(iy0 + kAltTile);
+    float* fdy = fdx + kAltTile;
+    int* red = reinterpret_cast<int*>(fdy + kAltTile);     // rectangle: x0, y0, width, height
+    const int n1 = 2 * r + 2, P = n1 * n1, rd = 2 * r + 1, K = rd * rd;
+    const int tiles_x = (W + kAltTW - 1) / kAltTW, tiles_y = (H + kAltTH - 1) / kAltTH;
+    int blk = blockIdx.x;
+    const int tx = blk % tiles_x; blk /= tiles_x;
+    const int ty = blk % tiles_y; blk /= tiles_y;
+    const int s = blk % S;
+    const int b = blk / S;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float* fmap2b = fmap2 + (size_t)b * H2 * W2 * C;
+
+    if (threadIdx.x < kAltTile) {
+        const int pw = tx * kAltTW + (threadIdx.x & (kAltTW - 1)), ph = ty * kAltTH + threadIdx.x / kAltTW;
+        float x = 2e6f, y = 2e6f;
+        if (pw < W && ph < H) {
+            const float* cp = coords + ((((size_t)b * S + s) * H + ph) * W + pw) * 2;
+            x = cp[0]; y = cp[1];
+        }
+        // coordinates far outside (or not finite) see nothing; the bound keeps the casts defined
+        const bool sane = fabsf(x) < 1e6f && fabsf(y) < 1e6f;
+        const float xf = sane ? floorf(x) : -1e6f, yf = sane ? floorf(y) : -1e6f;
+        const int x0 = (int)xf - r, y0 = (int)yf - r;
+        ix0[threadIdx.x] = x0; iy0[threadIdx.x] = y0;
+        fdx[threadIdx.x] = sane ? x - xf : 0.f; fdy[threadIdx.x] = sane ? y - yf : 0.f;
+        const bool meets = x0 + n1 > 0 && x0 < W2 && y0 + n1 > 0 && y0 < H2;
+        int xlo = meets ? x0 : INT_MAX, ylo = meets ? y0 : INT_MAX;
+        int xhi = meets ? x0 + n1 : INT_MIN, yhi = meets ? y0 + n1 : INT_MIN;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            xlo = min(xlo, __shfl_xor(xlo, o, 64)); ylo = min(ylo, __shfl_xor(ylo, o, 64));
+            xhi = max(xhi, __shfl_xor(xhi, o, 64)); yhi = max(yhi, __shfl_xor(yhi, o, 64));
+        }
+        if (threadIdx.x == 0) {
+            const bool any = xlo <= xhi;
+            const int ax = max(xlo, 0), ay = max(ylo, 0);
+            red[0] = ax; red[1] = ay;
+            red[2] = any ? min(xhi, W2) - ax : 0;
+            red[3] = any ? min(yhi, H2) - ay : 0;
+        }
+    }
+    __syncthreads();
+    const int rx0 = red[0], ry0 = red[1], rw = red[2], rh = red[3];
+    const int npos = rw * rh;
+    const bool any = rw > 0 && rh > 0;
+    const bool staged = any && npos <= kAltCap;
+
+    // where this lane's position of every pixel of the wave's row lives (-1: outside fmap2)
+    int off[kAltTW];
+    {
+        const int iy = lane / n1, ix = lane - iy * n1;
+#pragma unroll
+        for (int p = 0; p < kAltTW; ++p) {
+            const int yy = iy0[wv * kAltTW + p] + iy, xx = ix0[wv * kAltTW + p] + ix;
+            const bool ok = lane < P && yy >= 0 && yy < H2 && xx >= 0 && xx < W2;
+            off[p] = !ok ? -1 : staged ? ((yy - ry0) * rw + (xx - rx0)) * kAltStride
+                                       : (yy * W2 + xx) * C;
+        }
+    }
+    // what this thread copies into LDS per chunk (the rectangle does not move between chunks)
+    int goff[kAltStageIters];
+#pragma unroll
+    for (int t = 0; t < kAltStageIters; ++t) {
+        const int idx = threadIdx.x + 256 * t, pos = idx >> 2;
+        const int ry = pos / max(rw, 1), rx = pos - ry * max(rw, 1);
+        goff[t] = (staged && pos < npos) ? ((ry0 + ry) * W2 + rx0 + rx) * C + (idx & 3) * 4 : -1;
+    }
+    // the f1 chunk: thread -> (pixel, four channels)
+    const int fp = threadIdx.x >> 2;
+    const int fpw = tx * kAltTW + (fp & (kAltTW - 1)), fph = ty * kAltTH + fp / kAltTW;
+    const float* f1src = (fpw < W && fph < H)
+        ? fmap1 + (((size_t)b * H + fph) * W + fpw) * C + (threadIdx.x & 3) * 4 : nullptr;
+
+    float acc[kAltTW];
+#pragma unroll
+    for (int p = 0; p < kAltTW; ++p) acc[p] = 0.f;
+    const int nch = any ? C / kAltCh : 0;
+    // (Fetching the next chunk into registers while the current one is multiplied was measured
+    // slower, 8.4 against 7.5 ms over four levels: the loop is bound by its LDS reads, not by the
+    // fetch between the two barriers.)
+    for (int ch = 0; ch < nch; ++ch) {
+        __syncthreads();                       // the previous chunk has been consumed
+        if (staged) {
+#pragma unroll
+            for (int t = 0; t < kAltStageIters; ++t)
+                if (goff[t] >= 0) {
+                    const int idx = threadIdx.x + 256 * t;
+                    *reinterpret_cast<float4*>(reg + (idx >> 2) * kAltStride + (idx & 3) * 4) =
+                        *reinterpret_cast<const float4*>(fmap2b + goff[t] + ch * kAltCh);
+                }
+        }
+        *reinterpret_cast<float4*>(f1s + threadIdx.x * 4) =
+            f1src ? *reinterpret_cast<const float4*>(f1src + ch * kAltCh) : make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        if (staged) altcorr_row_dots<true>(acc, off, f1s + wv * kAltTW * kAltCh, reg);
+        else altcorr_row_dots<false>(acc, off, f1s + wv * kAltTW * kAltCh, fmap2b + ch * kAltCh);
+    }
+    __syncthreads();                           // reg becomes the output tile [K][64]
+    float* tile = reg;
+#pragma unroll
+    for (int p = 0; p < kAltTW; ++p) {
+        dots[wv * 64 + lane] = acc[p];
+        // same wave wrote and reads: LDS operations of a wave complete in order
+        __builtin_amdgcn_wave_barrier();
+        const int pi = wv * kAltTW + p;
+        const float dx = fdx[pi], dy = fdy[pi];
+        if (lane < K) {
+            const int i = lane / rd, j = lane - i * rd;
+            const float* e = dots + wv * 64 + i * n1 + j;
+            tile[lane * kAltTile + pi] = (1.f - dx) * (1.f - dy) * e[0] + dx * (1.f - dy) * e[1] +
+                                         (1.f - dx) * dy * e[n1] + dx * dy * e[n1 + 1];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    float* out = corr + (((size_t)b * S + s) * K) * H * W;
+    for (int k = threadIdx.x; k < K * kAltTile; k += 256) {
+        const int kk = k / kAltTile, pi = k - kk * kAltTile;
+        const int pw = tx * kAltTW + (pi & (kAltTW - 1)), ph = ty * kAltTH + pi / kAltTW;
+        if (pw < W && ph < H) out[((size_t)kk * H + ph) * W + pw] = tile[k];
+    }
+}
+
 // Adjoint with respect to both feature maps.  One wave per (b, s, h, w); the lanes first fold
 // corr_grad back onto the (2r+2)^2 integer positions (adjoint of the bilinear weights), then
 // own channels: for every position with a non-zero weight the pixel's fmap1 row is added into
@@ -460,6 +630,19 @@ extern "C" int vings_altcorr_forward(const float* fmap1, const float* fmap2, con
     if (B == 0) return VINGS_OK;
     VINGS_REQUIRE(fmap1 && fmap2 && coords && corr, "null pointer");
     VINGS_REQUIRE((((uintptr_t)fmap1 | (uintptr_t)fmap2) & 15) == 0, "feature maps must be 16-byte aligned");
+    if (r <= 3 && (C % kAltCh) == 0 && (long long)H2 * W2 * C < (1ll << 31)) {
+        const long long tiles = (long long)B * S * cdiv(H, kAltTH) * cdiv(W, kAltTW);
+        VINGS_REQUIRE(tiles < (1ll << 31), "grid too large");
+        // (per device, so not cached in a process-wide flag: a few microseconds per call)
+        VINGS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(altcorr_fwd_tile_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)kAltTileLds));
+        ProfScope prof(PROF_AUX, (hipStream_t)stream);
+        altcorr_fwd_tile_kernel<<<(int)tiles, 256, kAltTileLds, (hipStream_t)stream>>>(
+            fmap1, fmap2, coords, corr, B, S, H, W, H2, W2, C, r);
+        VINGS_LAUNCH_CHECK();
+        return VINGS_OK;
+    }
     const int n1 = 2 * r + 2, rd = 2 * r + 1;
     const size_t lds = sizeof(float) * ((size_t)kAltPx * C + 4 * n1 * n1 + (size_t)rd * rd * kAltPx);
     VINGS_REQUIRE(lds <= 160 * 1024, "window and channel count exceed the LDS of a CU");
