@@ -353,7 +353,12 @@ def main():
                         "per (8x8 pixel block, splat) pair where the algorithmic count has one "
                         "84-byte row per visible splat (an LDS accumulator per tile halves it and "
                         "was measured slower)"}
-    stage_ms = {k: round(v["ms"] / max(v["count"], 1), 4) for k, v in prof_all.items()}
+    # per view for the stages of the view step (binning is two timed calls: the sort and the
+    # tile order), per launch for everything else
+    views_timed = prof_all.get("blend_fwd", {}).get("count", 0)
+    per_view = {"project_fwd", "bin", "blend_fwd", "blend_bwd", "project_bwd", "adam", "loss"}
+    stage_ms = {k: round(v["ms"] / max(views_timed if (k in per_view and views_timed) else v["count"], 1), 4)
+                for k, v in prof_all.items()}
     if loop is not None:
         ev = loop["events"]
         stage_ms.update({"loop_score_top3": round(ev[0].elapsed_time(ev[1]), 3),

@@ -305,6 +305,30 @@ int vings_surfel_blend_backward_accumulate_lean(
     const float* bg, const uint8_t* pixel_mask, const float* final_T, const uint32_t* n_contrib,
     const float* dL_dcolor, const float* dL_dallmap, float* dgeom, void* stream);
 
+/* Tile scheduling of the blend passes (no counterpart in the reference: its CUDA grid takes the
+ * tiles in image order).  vings_surfel_tile_order writes a permutation of the T = ceil(W/16) *
+ * ceil(H/16) tiles, longest list first (256 length classes; the order inside a class is
+ * arbitrary), from the ranges vings_surfel_bin left.  The _ordered blend passes take their tiles
+ * in that order (workgroup b renders tile tile_order[b]; NULL = the default XCD-contiguous
+ * order), so a launch ends on its cheapest tiles and the workgroups dealt round-robin over the
+ * XCDs carry similar loads.  Outputs have the bits of the unordered passes (the gradient rows up
+ * to the order of their float atomics, as before).  `lean` != 0 selects the lean passes above;
+ * the backward adds into dgeom like vings_surfel_blend_backward_accumulate.  tile_order must be
+ * a permutation of 0..T-1: a tile missing from it is not rendered. */
+int vings_surfel_tile_order(int H, int W, const uint32_t* ranges, uint32_t* tile_order,
+                            void* stream);
+int vings_surfel_blend_forward_ordered(int lean, int H, int W, const uint32_t* ranges,
+                                       const uint32_t* vals_sorted, const float* geom,
+                                       const float* bg, const uint8_t* pixel_mask,
+                                       float* out_color, float* allmap, float* final_T,
+                                       uint32_t* n_contrib, const uint32_t* tile_order,
+                                       void* stream);
+int vings_surfel_blend_backward_accumulate_ordered(
+    int lean, int N, int H, int W, const uint32_t* ranges, const uint32_t* vals_sorted,
+    const float* geom, const float* bg, const uint8_t* pixel_mask, const float* final_T,
+    const uint32_t* n_contrib, const float* dL_dcolor, const float* dL_dallmap, float* dgeom,
+    const uint32_t* tile_order, void* stream);
+
 /* ------------------------------------------------------------------------
  * The view step under HIP stream capture (one graph per keyframe of the window, replayed every
  * iteration).  A graph has fixed buffers, so the view is binned into a fixed capacity, and the

@@ -513,3 +513,60 @@ def test_lean_blend_passes_equal_the_full_ones():
     assert int(vis.sum()) > 1000 and bool(torch.isfinite(b[vis]).all())
     scale = a[vis].abs().max(0).values
     assert bool(((a[vis] - b[vis]).abs().max(0).values <= 1e-5 * scale + 1e-12).all())
+
+
+def test_ordered_blend_passes_equal_the_default_order():
+    """The view step's blend passes take their tiles longest list first
+    (vings_surfel_tile_order + the _ordered passes): the order is a permutation of the tiles by
+    non-increasing length class, the forward planes have the bits of the default tile order and
+    the backward rows agree up to the order of their float atomics.  Odd image size, so that the
+    last tile row and column are partial, and a scene with empty tiles."""
+    from vings_mono_amd import harness
+    dev = torch.device("cuda:0")
+    W, H, n = 333, 190, 9000
+    raw = {k: v.to(dev).contiguous() for k, v in synth.make_splats(n, W, H, n_views=2, seed=83).items()}
+    raw["_xyz"][: n // 2, 0] -= 3.0          # pile half of the splats up on the left
+    gone = raw["_xyz"][:, 0] > 0.25 * raw["_xyz"][:, 2]
+    raw["_xyz"][gone, 2] = -5.0              # and clear the right of the image: empty tiles
+    intr = synth.intrinsic_for(W, H)
+    cam = harness.view_settings(torch.linalg.inv(synth.window_poses(2)[1]).to(dev), intr)
+    e = lambda *s: torch.empty(*s, device=dev)
+
+    def forward(ordered, lean):
+        surfel.ORDER_TILES = ordered
+        try:
+            o, s, r = e(n, 1), e(n, 2), e(n, 4)
+            dgeom = e(n, surfel.GRAD_STRIDE)
+            st, aux = surfel.rasterize_forward(raw["_xyz"], raw["_rgb"], o, s, r, cam,
+                                               raw=(raw["_opacity"], raw["_scaling"], raw["_rotation"]),
+                                               dgeom=dgeom, lean=lean)
+        finally:
+            surfel.ORDER_TILES = True
+        return st, aux, dgeom
+
+    g = torch.Generator(device="cpu").manual_seed(6)
+    g_color = torch.randn(3, H, W, generator=g).to(dev)
+    g_allmap = torch.randn(surfel.AUX_CHANNELS, H, W, generator=g).to(dev)
+    for lean in (False, True):
+        a, aux_a, dg_a = forward(False, lean)
+        b, aux_b, dg_b = forward(True, lean)
+        assert a.tile_order is None and b.tile_order is not None
+        T = a.ranges.shape[0]
+        order = b.tile_order.long()
+        assert torch.equal(torch.sort(order).values, torch.arange(T, device=dev))
+        lens = (b.ranges[:, 1] - b.ranges[:, 0]).long()
+        assert int(lens.min()) == 0 and int(lens.max()) > 100
+        cls = 255 - torch.clamp((lens.float() * (255.0 / float(lens.max()))).long(), max=255)
+        walked = cls[order]
+        assert bool((walked[1:] >= walked[:-1]).all())
+        for name in ("ranges", "radii", "n_contrib", "color", "allmap", "final_T"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), name
+        ga = g_allmap.clone()
+        if lean:
+            ga[[5, 7, 8]] = 0.0
+        ra = surfel.blend_backward(a, aux_a, g_color, ga, dgeom=dg_a, lean=lean)
+        rb = surfel.blend_backward(b, aux_b, g_color, ga, dgeom=dg_b, lean=lean)
+        torch.cuda.synchronize()
+        vis = a.radii > 0
+        scale = ra[vis].abs().max(0).values
+        assert bool(((ra[vis] - rb[vis]).abs().max(0).values <= 1e-5 * scale + 1e-12).all())

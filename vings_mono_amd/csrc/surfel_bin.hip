@@ -484,6 +484,46 @@ __global__ __launch_bounds__(256) void tile_depth_sort_kernel(
     }
 }
 
+// Tiles in the order the blend passes should take them: longest list first (counting sort over
+// 256 length classes, one workgroup).  Workgroups are dispatched in index order, so the launch
+// then ends on its cheapest tiles instead of on whatever the image's last rows hold, and
+// consecutive workgroups -- dealt round-robin over the XCDs -- carry similar loads.
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ ranges, int T,
+                                                          uint32_t* __restrict__ order) {
+    __shared__ uint32_t cnt[256];
+    __shared__ uint32_t smax;
+    if (threadIdx.x < 256) cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) smax = 1;
+    __syncthreads();
+    const uint2* rg = reinterpret_cast<const uint2*>(ranges);
+    uint32_t mx = 0;
+    for (int t = threadIdx.x; t < T; t += 1024) { const uint2 r = rg[t]; mx = max(mx, r.y - r.x); }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(&smax, mx);
+    __syncthreads();
+    const float scale = 255.f / (float)smax;
+    auto cls = [&](int t) { const uint2 r = rg[t]; return 255u - min(255u, (uint32_t)((float)(r.y - r.x) * scale)); };
+    for (int t = threadIdx.x; t < T; t += 1024) atomicAdd(&cnt[cls(t)], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) {      // exclusive scan of the 256 class counts by one wave, 4 per lane
+        uint32_t c[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c[k] = cnt[threadIdx.x * 4 + k]; sum += c[k]; }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(inc, o, 64);
+            if ((int)threadIdx.x >= o) inc += v;
+        }
+        uint32_t run = inc - sum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { cnt[threadIdx.x * 4 + k] = run; run += c[k]; }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 1024) order[atomicAdd(&cnt[cls(t)], 1u)] = (uint32_t)t;
+}
+
 static int bits_for(uint32_t span) {   // bits needed to hold values 0..span
     int bits = 0;
     while (bits < 32 && ((uint64_t)1 << bits) <= (uint64_t)span) ++bits;
@@ -607,4 +647,16 @@ extern "C" int vings_surfel_bin_speculative(int N, int H, int W, int64_t D_capac
     VINGS_REQUIRE(tail != nullptr && D_capacity > 0 && N > 0, "speculative binning needs a guess");
     return bin_impl(N, H, W, D_capacity, tail, depth, rect, tiles_touched, block_prefix,
                     keys_sorted, vals_sorted, ranges, workspace, workspace_bytes, stream);
+}
+
+extern "C" int vings_surfel_tile_order(int H, int W, const uint32_t* ranges, uint32_t* tile_order,
+                                       void* stream) {
+    VINGS_REQUIRE(H > 0 && W > 0, "sizes");
+    VINGS_REQUIRE(ranges && tile_order, "null pointer");
+    VINGS_REQUIRE(((uintptr_t)ranges & 7) == 0, "ranges must be 8-byte aligned");
+    const int T = ((W + 15) / 16) * ((H + 15) / 16);
+    ProfScope prof(PROF_BIN, (hipStream_t)stream);
+    tile_order_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(ranges, T, tile_order);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
 }

@@ -151,10 +151,13 @@ __global__ __launch_bounds__(256, 7) void blend_fwd_kernel(
     int H, int W, int gx, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ vals,
     const float* __restrict__ geom, const float* __restrict__ bg,
     const uint8_t* __restrict__ pixel_mask, float* __restrict__ out_color,
-    float* __restrict__ allmap, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
+    float* __restrict__ allmap, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+    const uint32_t* __restrict__ tile_order) {
     __shared__ float4 rec[kBatch * (kRec4 - 1)];
     __shared__ unsigned long long hit[16];
-    const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
+    // (tile_order: a permutation of the tiles, longest list first; without it the tiles are
+    // handed out XCD-contiguously)
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : xcd_contiguous(blockIdx.x, gridDim.x);
     const int tx = tile % gx, ty = tile / gx;
     // wave w renders block (w & 1, w >> 1) of the tile; lane l is pixel (l & 7, l >> 3) of it
     const int px = tx * 16 + kBlk * ((threadIdx.x >> 6) & 1) + (threadIdx.x & 7);
@@ -345,12 +348,13 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
     const float* __restrict__ geom, const float* __restrict__ bg,
     const uint8_t* __restrict__ pixel_mask, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
-    const float* __restrict__ dL_dallmap, float* __restrict__ dgeom) {
+    const float* __restrict__ dL_dallmap, float* __restrict__ dgeom,
+    const uint32_t* __restrict__ tile_order) {
     __shared__ float4 rec[kBatchBwd * (kRec4 - 1)];
     __shared__ uint32_t ids[kBatchBwd];
     __shared__ unsigned long long hit[16];
     __shared__ uint32_t wmax[4];
-    const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : xcd_contiguous(blockIdx.x, gridDim.x);
     const int tx = tile % gx, ty = tile / gx;
     // wave w renders block (w & 1, w >> 1) of the tile; lane l is pixel (l & 7, l >> 3) of it
     const int px = tx * 16 + kBlk * ((threadIdx.x >> 6) & 1) + (threadIdx.x & 7);
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
                          : (slot_ >> 2) == 3 ? 12 : 2;
     const int fetch_from = ((fetch_row << 4) | pos_of_k) << 2;         // byte address for ds_bpermute
     const float flush_sign = lane_ < 6 ? -1.f : 1.f;
-    const bool low8 = (lane_ & 8) == 0, low4 = (lane_ & 4) == 0, low2 = (lane_ & 2) == 0;
+    const bool low2 = (lane_ & 2) == 0;
     const float fx = (float)px, fy = (float)py;
     const uint32_t r0 = ranges[2 * tile];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -588,7 +592,8 @@ using namespace vings;
 static int blend_forward_impl(bool lean, int H, int W, const uint32_t* ranges,
                               const uint32_t* vals_sorted, const float* geom, const float* bg,
                               const uint8_t* pixel_mask, float* out_color, float* allmap,
-                              float* final_T, uint32_t* n_contrib, void* stream) {
+                              float* final_T, uint32_t* n_contrib, void* stream,
+                              const uint32_t* tile_order = nullptr) {
     VINGS_REQUIRE(H > 0 && W > 0, "sizes");
     VINGS_REQUIRE(ranges && bg && out_color && allmap && final_T && n_contrib, "null pointer");
     VINGS_REQUIRE(((uintptr_t)geom & 15) == 0, "geom must be 16-byte aligned");
@@ -596,10 +601,12 @@ static int blend_forward_impl(bool lean, int H, int W, const uint32_t* ranges,
     ProfScope prof(PROF_BLEND_FWD, (hipStream_t)stream);
     if (lean)
         blend_fwd_kernel<true><<<gx * gy, 256, 0, (hipStream_t)stream>>>(
-            H, W, gx, ranges, vals_sorted, geom, bg, pixel_mask, out_color, allmap, final_T, n_contrib);
+            H, W, gx, ranges, vals_sorted, geom, bg, pixel_mask, out_color, allmap, final_T, n_contrib,
+            tile_order);
     else
         blend_fwd_kernel<false><<<gx * gy, 256, 0, (hipStream_t)stream>>>(
-            H, W, gx, ranges, vals_sorted, geom, bg, pixel_mask, out_color, allmap, final_T, n_contrib);
+            H, W, gx, ranges, vals_sorted, geom, bg, pixel_mask, out_color, allmap, final_T, n_contrib,
+            tile_order);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }
@@ -627,7 +634,8 @@ static int blend_backward_impl(bool clear, bool lean, int N, int H, int W, const
                                            const float* bg, const uint8_t* pixel_mask,
                                            const float* final_T, const uint32_t* n_contrib,
                                            const float* dL_dcolor, const float* dL_dallmap,
-                                           float* dgeom, void* stream) {
+                                           float* dgeom, void* stream,
+                                           const uint32_t* tile_order = nullptr) {
     VINGS_REQUIRE(N >= 0 && H > 0 && W > 0, "sizes");
     if (N == 0) return VINGS_OK;
     VINGS_REQUIRE(ranges && bg && final_T && n_contrib && dL_dcolor && dL_dallmap && dgeom,
@@ -640,11 +648,11 @@ static int blend_backward_impl(bool clear, bool lean, int N, int H, int W, const
     if (lean)
         blend_bwd_kernel<true><<<gx * gy, 256, 0, s>>>(H, W, gx, ranges, vals_sorted, geom, bg,
                                                        pixel_mask, final_T, n_contrib, dL_dcolor,
-                                                       dL_dallmap, dgeom);
+                                                       dL_dallmap, dgeom, tile_order);
     else
         blend_bwd_kernel<false><<<gx * gy, 256, 0, s>>>(H, W, gx, ranges, vals_sorted, geom, bg,
                                                         pixel_mask, final_T, n_contrib, dL_dcolor,
-                                                        dL_dallmap, dgeom);
+                                                        dL_dallmap, dgeom, tile_order);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }
@@ -697,4 +705,23 @@ extern "C" int vings_surfel_blend_backward_accumulate_lean(
     const float* dL_dcolor, const float* dL_dallmap, float* dgeom, void* stream) {
     return blend_backward_impl(false, true, N, H, W, ranges, vals_sorted, geom, bg, pixel_mask,
                                final_T, n_contrib, dL_dcolor, dL_dallmap, dgeom, stream);
+}
+
+extern "C" int vings_surfel_blend_forward_ordered(int lean, int H, int W, const uint32_t* ranges,
+                                                  const uint32_t* vals_sorted, const float* geom,
+                                                  const float* bg, const uint8_t* pixel_mask,
+                                                  float* out_color, float* allmap, float* final_T,
+                                                  uint32_t* n_contrib, const uint32_t* tile_order,
+                                                  void* stream) {
+    return blend_forward_impl(lean != 0, H, W, ranges, vals_sorted, geom, bg, pixel_mask, out_color,
+                              allmap, final_T, n_contrib, stream, tile_order);
+}
+
+extern "C" int vings_surfel_blend_backward_accumulate_ordered(
+    int lean, int N, int H, int W, const uint32_t* ranges, const uint32_t* vals_sorted,
+    const float* geom, const float* bg, const uint8_t* pixel_mask, const float* final_T,
+    const uint32_t* n_contrib, const float* dL_dcolor, const float* dL_dallmap, float* dgeom,
+    const uint32_t* tile_order, void* stream) {
+    return blend_backward_impl(false, lean != 0, N, H, W, ranges, vals_sorted, geom, bg, pixel_mask,
+                               final_T, n_contrib, dL_dcolor, dL_dallmap, dgeom, stream, tile_order);
 }

@@ -52,8 +52,11 @@ def _f32c(t, name):
 class SurfelForwardState:
     """Device buffers produced by one forward pass (kept for backward / tests)."""
     __slots__ = ("N", "H", "W", "D", "geom", "depth", "radii", "rect", "tiles_touched",
-                 "block_prefix", "keys", "vals", "ranges", "final_T", "n_contrib", "color",
+                 "block_prefix", "keys", "vals", "ranges", "tile_order", "final_T", "n_contrib", "color",
                  "allmap", "tail_ptr", "_keep")
+
+    def __init__(self):
+        self.tile_order = None      # set when the blend passes take their tiles in a chosen order
 
 
 def set_tight_binning(on):
@@ -118,6 +121,7 @@ def view_importance(means3D, colors, opacities, scales, rotations, settings, out
     return out, st.radii
 
 
+ORDER_TILES = os.environ.get("VINGS_ORDER_TILES", "1") != "0"   # blend passes of the view step take their tiles longest list first
 SPECULATE = os.environ.get("VINGS_SPECULATE", "1") != "0"   # launch sort + blend before the host has the instance count (see _forward)
 _D_HINT = {}       # (device index, H, W) -> (instance count, depth key bits) of the latest view
 
@@ -180,6 +184,16 @@ def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys,
         st.allmap = torch.empty((AUX_CHANNELS, H, W), dtype=torch.float32, device=dev)
         st.final_T = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         st.n_contrib = torch.empty((2, H, W), dtype=torch.int32, device=dev)
+        if ORDER_TILES and dgeom is not None:
+            # the mapper's view step: both blend passes take the tiles longest list first
+            st.tile_order = torch.empty(T, dtype=torch.int32, device=dev)
+            check(L.vings_surfel_tile_order(H, W, ptr(st.ranges), ptr(st.tile_order), stream),
+                  "vings_surfel_tile_order")
+            check(L.vings_surfel_blend_forward_ordered(
+                1 if lean else 0, H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg),
+                ptr(mask), ptr(st.color), ptr(st.allmap), ptr(st.final_T), ptr(st.n_contrib),
+                ptr(st.tile_order), stream), "vings_surfel_blend_forward_ordered")
+            return
         fwd = L.vings_surfel_blend_forward_lean if lean else L.vings_surfel_blend_forward
         check(fwd(H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg), ptr(mask),
                   ptr(st.color), ptr(st.allmap), ptr(st.final_T), ptr(st.n_contrib), stream),
@@ -297,10 +311,14 @@ def rasterize_forward_fixed(means3D, colors, opacities, scales, rotations, setti
     st.allmap = torch.empty((AUX_CHANNELS, H, W), dtype=torch.float32, device=dev)
     st.final_T = torch.empty((3, H, W), dtype=torch.float32, device=dev)
     st.n_contrib = torch.empty((2, H, W), dtype=torch.int32, device=dev)
-    fwd = L.vings_surfel_blend_forward if flow is not None else L.vings_surfel_blend_forward_lean
-    check(fwd(H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg), ptr(mask), ptr(st.color),
-              ptr(st.allmap), ptr(st.final_T), ptr(st.n_contrib), stream),
-          "vings_surfel_blend_forward")
+    if ORDER_TILES:
+        st.tile_order = torch.empty(T, dtype=torch.int32, device=dev)
+        check(L.vings_surfel_tile_order(H, W, ptr(st.ranges), ptr(st.tile_order), stream),
+              "vings_surfel_tile_order")
+    check(L.vings_surfel_blend_forward_ordered(
+        0 if flow is not None else 1, H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg),
+        ptr(mask), ptr(st.color), ptr(st.allmap), ptr(st.final_T), ptr(st.n_contrib),
+        ptr(st.tile_order), stream), "vings_surfel_blend_forward_ordered")
     st.D = None          # on the device / in count_words only
     st.keys = None
     st.tail_ptr = tail   # device address of the count words (for the guarded entry points)
@@ -319,6 +337,12 @@ def blend_backward(st, aux, g_color, g_allmap, dgeom=None, lean=False):
     dev = st.geom.device
     if lean and dgeom is None:
         raise _lib.VingsError("the lean backward pass adds into rows the forward pass cleared: pass dgeom")
+    if dgeom is not None and st.tile_order is not None:
+        check(L.vings_surfel_blend_backward_accumulate_ordered(
+            1 if lean else 0, N, H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg), ptr(mask),
+            ptr(st.final_T), ptr(st.n_contrib), ptr(g_color), ptr(g_allmap), ptr(dgeom),
+            ptr(st.tile_order), stream_ptr(dev)), "vings_surfel_blend_backward_accumulate_ordered")
+        return dgeom
     if dgeom is not None:
         bwd = (L.vings_surfel_blend_backward_accumulate_lean if lean
                else L.vings_surfel_blend_backward_accumulate)
