@@ -61,9 +61,10 @@ int vings_abi_version(void);
  * in : means3D[N,3] scales[N,2] rotations[N,4](w,x,y,z) opacities[N]
  *      colors[N,3] flow[N,2] or NULL; viewmatrix[16] projmatrix[16] as the
  *      flat storage of the reference's transposed matrices (cameras.py:58-60)
- * out: geom[N,24]  packed record {T[9], xy[2], normal[3], opacity, rgb[3], flow[2],
+ * out: geom[N,24]  packed record {Tu[3], x, Tv[3], y, Tw[3], normal[3], opacity, rgb[3],
+ *                  flow[2]} (T = rows of the pixel homography, (x, y) = pixel centre) +
  *                  box[4] = xmin,xmax,ymin,ymax of the pixels the splat can reach with
- *                  alpha >= 1/255 (conservative; lets a wave skip the splat)}
+ *                  alpha >= 1/255 (conservative; lets a wave skip the splat)
  *                  (rows of culled splats are left untouched)
  *      depth[N] radii[N](int32) rect[N,4](int32 x0,y0,x1,y1 in tiles; packed form under tight binning, see vings_surfel_set_tight_binning)
  *      tiles_touched[N](uint32)

@@ -138,8 +138,9 @@ def test_forward_parity(case, oracle32, oracle64, tight):
     vis = ref["radii"] > 0
     np.testing.assert_array_equal(st.depth.cpu().numpy()[:vis.shape[0]][vis], ref["depth"][vis])
     geom = st.geom.cpu().numpy()[:vis.shape[0]]
-    np.testing.assert_array_equal(geom[vis, 0:9], ref["transmat"][vis])
-    np.testing.assert_array_equal(geom[vis, 9:11], ref["xy"][vis])
+    # record layout: {Tu, x} {Tv, y} {Tw, n0} {n1, n2, opacity, r} ...
+    np.testing.assert_array_equal(geom[vis][:, [0, 1, 2, 4, 5, 6, 8, 9, 10]], ref["transmat"][vis])
+    np.testing.assert_array_equal(geom[vis][:, [3, 7]], ref["xy"][vis])
     np.testing.assert_array_equal(geom[vis, 11:15], ref["normal_opacity"][vis])
     # ---- floating outputs ----
     full64 = oracle_forward(oracle64, sc)

@@ -49,8 +49,8 @@ __device__ __forceinline__ uint32_t block_mask(const float4* r, const float4 bx,
             boxm |= 1u << s;
     }
     if (boxm == 0 || bx.x < -1e29f) return boxm;   // unbounded box: no conic bound either
-    const float Tu0 = r[0].x, Tu1 = r[0].y, Tu2 = r[0].z, Tv0 = r[0].w, Tv1 = r[1].x, Tv2 = r[1].y;
-    const float Tw0 = r[1].z, Tw1 = r[1].w, Tw2 = r[2].x, cx = r[2].y, cy = r[2].z, o = r[3].z;
+    const float Tu0 = r[0].x, Tu1 = r[0].y, Tu2 = r[0].z, Tv0 = r[1].x, Tv1 = r[1].y, Tv2 = r[1].z;
+    const float Tw0 = r[2].x, Tw1 = r[2].y, Tw2 = r[2].z, cx = r[0].w, cy = r[1].w, o = r[3].z;
     const float rc = 2.f * __logf(255.f * o) * 1.002f + 0.02f;
     const float Ax = Tv1 * Tw2 - Tv2 * Tw1, Ay = Tv2 * Tw0 - Tv0 * Tw2, Az = Tv0 * Tw1 - Tv1 * Tw0;
     const float Bx = Tw1 * Tu2 - Tw2 * Tu1, By = Tw2 * Tu0 - Tw0 * Tu2, Bz = Tw0 * Tu1 - Tw1 * Tu0;

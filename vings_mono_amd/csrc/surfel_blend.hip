@@ -63,10 +63,9 @@ __device__ __forceinline__ Rec5 load_rec(const float4* __restrict__ r) {
 
 __device__ __forceinline__ Splat unpack(const Rec5& q) {
     Splat s;
-    s.Tu[0] = q.a.x; s.Tu[1] = q.a.y; s.Tu[2] = q.a.z;
-    s.Tv[0] = q.a.w; s.Tv[1] = q.b.x; s.Tv[2] = q.b.y;
-    s.Tw[0] = q.b.z; s.Tw[1] = q.b.w; s.Tw[2] = q.c.x;
-    s.cx = q.c.y; s.cy = q.c.z;
+    s.Tu[0] = q.a.x; s.Tu[1] = q.a.y; s.Tu[2] = q.a.z; s.cx = q.a.w;
+    s.Tv[0] = q.b.x; s.Tv[1] = q.b.y; s.Tv[2] = q.b.z; s.cy = q.b.w;
+    s.Tw[0] = q.c.x; s.Tw[1] = q.c.y; s.Tw[2] = q.c.z;
     s.n[0] = q.c.w; s.n[1] = q.d.x; s.n[2] = q.d.y;
     s.opa = q.d.z;
     s.rgb[0] = q.d.w; s.rgb[1] = q.e.x; s.rgb[2] = q.e.y;
@@ -372,9 +371,11 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
     // slot is c; one lane of that row presents it, and the lane whose component lives in that
     // slot fetches it from there.
     const int lane_ = threadIdx.x & 63;
-    // (components 11 and 14 trade places inside the reduction, so that 11 pairs with 15: both
-    // are the blend weight times a per-pixel constant, see keep14 below)
-    const int slot_ = lane_ == 11 ? 14 : lane_ == 14 ? 11 : lane_;
+    // slot of the reduction that holds component t of the gradient row (the pairs of the first
+    // step are chosen for what they cost, see below)
+    constexpr unsigned char kSlotOf[kGrad] = {0, 2, 4, 1, 3, 5, 6, 7, 8, 10, 11, 14, 12, 13, 9, 15,
+                                              16, 17, 18, 19};
+    const int slot_ = kSlotOf[lane_ < kGrad ? lane_ : 0];
     const int fetch_row = (((slot_ & 3) & 1) << 1) | ((slot_ & 3) >> 1);
     // lane of a row that ends up with register k of the row sums (see the reduction below)
     const int pos_of_k = (slot_ >> 2) == 0 ? 0 : (slot_ >> 2) == 1 ? 8 : (slot_ >> 2) == 2 ? 4
@@ -382,7 +383,17 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
     const int fetch_from = ((fetch_row << 4) | pos_of_k) << 2;         // byte address for ds_bpermute
     const float flush_sign = lane_ < 6 ? -1.f : 1.f;
     const bool low2 = (lane_ & 2) == 0;
-    const float fx = (float)px, fy = (float)py;
+    // The upper half of the wave works with the two pixel axes exchanged: it reads {Tv, y} where
+    // the lower half reads {Tu, x} (twin slots of the record) and uses (py, px) for (px, py).
+    // The ray/splat intersection changes sign as a whole (p = k x l becomes l x k), which
+    // leaves sx, sy, rho, depth and alpha as they are; of the gradients, dL/dk and dL/dl change
+    // places, so do the two components of dL/dxy, and dL/dTw is symmetric in the exchange.
+    // The first step of the reduction sums exactly such pairs over lanes l / l+32 and hands one
+    // of each pair to either half: with the exchange every lane already holds the component its
+    // half keeps in the same register, and eight selects per (wave, splat) pair go away.
+    const bool hi_half = (threadIdx.x & 32) != 0;
+    const int twinA = hi_half ? 1 : 0, twinB = hi_half ? 0 : 1;
+    const float fx = hi_half ? (float)py : (float)px, fy = hi_half ? (float)px : (float)py;
     const uint32_t r0 = ranges[2 * tile];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 
@@ -458,7 +469,12 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
             const int j = lw * 64 + bit;
             wm &= ~(1ull << bit);
             const uint32_t pos = bstart + j;
-            const Splat s = unpack(load_rec(rec + j * (kRec4 - 1)));
+            Rec5 q5;
+            {
+                const float4* rj = rec + j * (kRec4 - 1);
+                q5.a = rj[twinA]; q5.b = rj[twinB]; q5.c = rj[2]; q5.d = rj[3]; q5.e = rj[4];
+            }
+            const Splat s = unpack(q5);
             Hit h;
             const bool c = eval_hit(s, fx, fy, h) & (pos < last);
             if (__ballot(c) == 0ull) continue;  // wave-uniform: nobody in the strip is touched
@@ -492,7 +508,7 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
             float dL_dz = 2.f * w * (m * A_final - M1f) * gDist * dm_dd + w * gD;
             if (!kLean) dL_dz += (c & (pos + 1 == medc)) ? gMed : 0.f;
             float g[kGrad];
-            g[11] = G * dL_dalpha;     // component 14 (slot 11)
+            g[9] = G * dL_dalpha;      // dL/dopacity (slot 9)
             // (slots 12..19: formed in the reduction from the constants chosen above)
             const float a = -(s.opa * dL_dalpha) * G;  // dL/drho * -2, zero for idle lanes
             const float sx = c3 ? h.sx : 0.f, sy = c3 ? h.sy : 0.f, rz = c3 ? h.rz : 0.f;
@@ -507,14 +523,15 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
             const float dly = dpz * h.kx - dpx * h.kz;
             const float dlz = dpx * h.ky - dpy * h.kx;
             // dL/dTu = -dk and dL/dTv = -dl: the sign is applied once per splat at the flush
-            g[0] = dkx; g[1] = dky; g[2] = dkz;
-            g[3] = dlx; g[4] = dly; g[5] = dlz;
+            // (slots 2i / 2i+1 of a pair: in the upper half the two registers hold each other's
+            // component, which is the one that half keeps)
+            g[0] = dkx; g[1] = dlx; g[2] = dky; g[3] = dly; g[4] = dkz; g[5] = dlz;
             g[6] = fx * dkx + fy * dlx + dL_dz * sx;
             g[7] = fx * dky + fy * dly + dL_dz * sy;
             g[8] = fx * dkz + fy * dlz + dL_dz;
             const float a2 = c3 ? 0.f : a * kFilterInvSq;  // low-pass filter drives G instead
-            g[9] = a2 * h.dx;
-            g[10] = a2 * h.dy;
+            g[10] = a2 * h.dx;
+            g[11] = a2 * h.dy;
             {
                 // Transposing reduction.  Step 1 sums a PAIR of components over lanes l / l+32
                 // and leaves one component per half: each lane keeps the component its half
@@ -540,6 +557,7 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
                         else if (i == 6) { mine[i] = w * keep12; send = w * send12; }
                         else if (i == 8) { mine[i] = w * keep16; send = w * send16; }
                         else if (i == 9) { mine[i] = w * keep18; send = w * send18; }
+                        else if (i <= 2 || i == 5) { mine[i] = g[2 * i]; send = g[2 * i + 1]; }
                         else { mine[i] = lo ? g[2 * i] : g[2 * i + 1]; send = lo ? g[2 * i + 1] : g[2 * i]; }
                         theirs[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(
                             partner, __builtin_bit_cast(int, send)));

@@ -189,9 +189,11 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
             float fl0 = 0.f, fl1 = 0.f;
             if (flow) { fl0 = flow[2 * i]; fl1 = flow[2 * i + 1]; }
             float4 rr[6];
-            rr[0] = make_float4(f.A[0][0], f.A[0][1], f.A[0][2], f.A[1][0]);
-            rr[1] = make_float4(f.A[1][1], f.A[1][2], f.A[2][0], f.A[2][1]);
-            rr[2] = make_float4(f.A[2][2], cx, cy, f.mult * f.n[0]);
+            // {Tu, cx} {Tv, cy} {Tw, n0}: the two pixel axes sit in twin slots, so a lane of the
+            // blend backward can read them exchanged (see blend_bwd_kernel)
+            rr[0] = make_float4(f.A[0][0], f.A[0][1], f.A[0][2], cx);
+            rr[1] = make_float4(f.A[1][0], f.A[1][1], f.A[1][2], cy);
+            rr[2] = make_float4(f.A[2][0], f.A[2][1], f.A[2][2], f.mult * f.n[0]);
             rr[3] = make_float4(f.mult * f.n[1], f.mult * f.n[2], o, c0);
             rr[4] = make_float4(c1, c2, fl0, fl1);
             // Conservative pixel box of alpha >= 1/255: alpha = o * exp(-rho/2) with
