@@ -424,7 +424,11 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
             gF0 = dL_dallmap[7 * HW + pix]; gF1 = dL_dallmap[8 * HW + pix];
         }
     }
-    const float A_final = 1.f - T_final;
+    // The distortion term enters through the final moments of the pixel only:
+    //   (M2 + m^2 A - 2 m M1) gDist + gA = P0 + m (m P1 + P2)       (share of S)
+    //   2 (m A - M1) gDist               = m (2 P1) + P2            (share of dL/ddepth)
+    const float P1 = (1.f - T_final) * gDist, P2 = -2.f * M1f * gDist, P0 = gA + M2f * gDist;
+    const float P1x2 = P1 + P1;
     const float bg_dot = bg[0] * gC0 + bg[1] * gC1 + bg[2] * gC2;
     const float gabs = fabsf(gC0) + fabsf(gC1) + fabsf(gC2);
     // Components 11/15, 12/13, 16/17 and 18/19 are the blend weight times a per-pixel constant,
@@ -493,9 +497,8 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
             const float rd = rcp_fast(depth);
             const float m = c1 * (1.f - kNearN * rd);
             const float dm_dd = c2 * rd * rd;
-            const float Wd = (M2f + m * m * A_final - 2.f * m * M1f) * gDist;
             // S = sum over channels of value * dL/dchannel (alpha channel value is 1)
-            float S = gA + Wd;
+            float S = P0 + m * (m * P1 + P2);
             S += s.rgb[0] * gC0 + s.rgb[1] * gC1 + s.rgb[2] * gC2;
             if (!kLean) S += s.fl[0] * gF0 + s.fl[1] * gF1;
             S += s.n[0] * gN0 + s.n[1] * gN1 + s.n[2] * gN2;
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
             B = c ? Bn : B;
             S_last = c ? S : S_last;
             last_alpha = c ? alpha : last_alpha;
-            float dL_dz = 2.f * w * (m * A_final - M1f) * gDist * dm_dd + w * gD;
+            float dL_dz = w * ((m * P1x2 + P2) * dm_dd) + w * gD;
             if (!kLean) dL_dz += (c & (pos + 1 == medc)) ? gMed : 0.f;
             float g[kGrad];
             g[9] = G * dL_dalpha;      // dL/dopacity (slot 9)
