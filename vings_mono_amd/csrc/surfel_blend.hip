@@ -430,6 +430,7 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
     const float P1 = (1.f - T_final) * gDist, P2 = -2.f * M1f * gDist, P0 = gA + M2f * gDist;
     const float P1x2 = P1 + P1;
     const float bg_dot = bg[0] * gC0 + bg[1] * gC1 + bg[2] * gC2;
+    const float Tbg = T_final * bg_dot;          // background share of dL/dalpha, times (1 - alpha)
     const float gabs = fabsf(gC0) + fabsf(gC1) + fabsf(gC2);
     // Components 11/15, 12/13, 16/17 and 18/19 are the blend weight times a per-pixel constant,
     // and the first reduction step hands one of each pair to the other half of the wave: which
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
             const float G = c ? h.G : 0.f;
             // distortion weight of this splat (the per-pixel moments are final ones)
             const float rd = rcp_fast(depth);
-            const float m = c1 * (1.f - kNearN * rd);
+            const float m = fmaf(rd, -c1 * kNearN, c1);       // c1 (1 - near / depth)
             const float dm_dd = c2 * rd * rd;
             // S = sum over channels of value * dL/dchannel (alpha channel value is 1)
             float S = P0 + m * (m * P1 + P2);
@@ -503,8 +504,8 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
             if (!kLean) S += s.fl[0] * gF0 + s.fl[1] * gF1;
             S += s.n[0] * gN0 + s.n[1] * gN1 + s.n[2] * gN2;
             S += depth * gD;
-            const float Bn = last_alpha * S_last + (1.f - last_alpha) * B;
-            const float dL_dalpha = c ? (S - Bn) * T - (T_final * r_one_m) * bg_dot : 0.f;
+            const float Bn = fmaf(last_alpha, S_last - B, B);
+            const float dL_dalpha = c ? (S - Bn) * T - r_one_m * Tbg : 0.f;
             B = c ? Bn : B;
             S_last = c ? S : S_last;
             last_alpha = c ? alpha : last_alpha;
