@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 7) void blend_fwd_kernel(
     const int wv = threadIdx.x >> 6;
 
     float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, F0 = 0, F1 = 0;
-    float T = 1.f, Dd = 0, M1 = 0, M2 = 0, dist = 0, med = 0;
+    float T = 1.f, Dd = 0, M1d = 0, M2 = 0, dist = 0, med = 0;   // M1d = 2 M1 (exactly: doubling does not round)
     uint32_t last = 0, medc = 0;
     const float c1 = kFarN / (kFarN - kNearN);
 
@@ -203,11 +203,13 @@ __global__ __launch_bounds__(256, 7) void blend_fwd_kernel(
                 const float w = c ? h.alpha * T : 0.f;
                 const float depth = c ? h.depth : 1.f;
                 const float A = 1.f - T;
-                const float m1 = c1 * (1.f - kNearN * rcp_fast(depth));
-                dist += (m1 * m1 * A + M2 - 2.f * m1 * M1) * w;
+                const float m1 = fmaf(rcp_fast(depth), -c1 * kNearN, c1);   // c1 (1 - near / depth)
+                // (m1^2 A + M2 - 2 m1 M1) w
+                dist = fmaf(fmaf(m1, fmaf(m1, A, -M1d), M2), w, dist);
                 Dd += depth * w;
-                M1 += m1 * w;
-                M2 += m1 * m1 * w;
+                const float mw = m1 * w;
+                M1d = fmaf(2.f, mw, M1d);
+                M2 = fmaf(m1, mw, M2);
                 if (!kLean) {
                     const bool md = c & (T > 0.5f);
                     med = md ? depth : med;
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256, 7) void blend_fwd_kernel(
         }
     }
     if (!inside) return;
-    final_T[pix] = T; final_T[HW + pix] = M1; final_T[2 * HW + pix] = M2;
+    final_T[pix] = T; final_T[HW + pix] = 0.5f * M1d; final_T[2 * HW + pix] = M2;
     n_contrib[pix] = last; n_contrib[HW + pix] = medc;
     if (masked) {
         out_color[pix] = bg[0]; out_color[HW + pix] = bg[1]; out_color[2 * HW + pix] = bg[2];
