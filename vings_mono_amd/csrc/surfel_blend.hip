@@ -99,7 +99,9 @@ __device__ __forceinline__ bool eval_hit(const Splat& s, float fx, float fy, Hit
     // (-0.5f * rho) * log2(e), and halving is exact, so rho * (-log2(e) / 2) has the same bits
     h.G = __builtin_amdgcn_exp2f(rho * __uint_as_float(0xbf38aa3bu));
     h.alpha = fminf(kAlphaMax, s.opa * h.G);
-    return (h.pz != 0.f) & !(h.depth < kNearN) & !(rho < 0.f) & (h.alpha >= kAlphaMin);
+    // (the reference's test rho < 0 can never fire: rho is a minimum of sums of squares, and a
+    // NaN fails alpha >= 1/255 below)
+    return (h.pz != 0.f) & !(h.depth < kNearN) & (h.alpha >= kAlphaMin);
 }
 
 // Gather this lane's record of the batch into LDS and publish, per 8x8 block of the
@@ -511,12 +513,12 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
             B = c ? Bn : B;
             S_last = c ? S : S_last;
             last_alpha = c ? alpha : last_alpha;
-            float dL_dz = w * ((m * P1x2 + P2) * dm_dd) + w * gD;
+            float dL_dz = w * fmaf(fmaf(m, P1x2, P2), dm_dd, gD);
             if (!kLean) dL_dz += (c & (pos + 1 == medc)) ? gMed : 0.f;
             float g[kGrad];
             g[9] = G * dL_dalpha;      // dL/dopacity (slot 9)
             // (slots 12..19: formed in the reduction from the constants chosen above)
-            const float a = -(s.opa * dL_dalpha) * G;  // dL/drho * -2, zero for idle lanes
+            const float a = -s.opa * g[9];             // dL/drho * -2, zero for idle lanes
             const float sx = c3 ? h.sx : 0.f, sy = c3 ? h.sy : 0.f, rz = c3 ? h.rz : 0.f;
             const float dsx = a * sx + dL_dz * s.Tw[0];
             const float dsy = a * sy + dL_dz * s.Tw[1];
