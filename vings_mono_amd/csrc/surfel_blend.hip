@@ -75,9 +75,17 @@ __device__ __forceinline__ Splat unpack(const Rec5& q) {
 
 struct Hit {
     float kx, ky, kz, lx, ly, lz, pz, rz, sx, sy, rho3d, rho2d, dx, dy, depth, G, alpha;
+    bool on_splat;   // the ray/splat intersection (not the low-pass disc) drives G and the depth
 };
 
 // Ray / splat intersection and opacity at pixel (fx, fy); false = no contribution.
+// kForGrad (the backward pass): sx, sy and rz come back as zeros wherever the low-pass disc
+// drives the pixel instead of the intersection -- there the depth is the centre's and no
+// gradient flows through the intersection -- and the depth is formed from those selected
+// values.  That also makes them finite in EVERY lane (an intersection at infinity never beats
+// the disc), which is what lets the caller run idle lanes through the gradient algebra with
+// alpha = 0 and nothing else neutralised.
+template <bool kForGrad = false>
 __device__ __forceinline__ bool eval_hit(const Splat& s, float fx, float fy, Hit& h) {
     h.kx = fx * s.Tw[0] - s.Tu[0]; h.ky = fx * s.Tw[1] - s.Tu[1]; h.kz = fx * s.Tw[2] - s.Tu[2];
     h.lx = fy * s.Tw[0] - s.Tv[0]; h.ly = fy * s.Tw[1] - s.Tv[1]; h.lz = fy * s.Tw[2] - s.Tv[2];
@@ -94,7 +102,13 @@ __device__ __forceinline__ bool eval_hit(const Splat& s, float fx, float fy, Hit
     h.dx = s.cx - fx; h.dy = s.cy - fy;
     h.rho2d = kFilterInvSq * (h.dx * h.dx + h.dy * h.dy);
     const float rho = fminf(h.rho3d, h.rho2d);
-    h.depth = (h.rho3d <= h.rho2d) ? (h.sx * s.Tw[0] + h.sy * s.Tw[1]) + s.Tw[2] : s.Tw[2];
+    h.on_splat = h.rho3d <= h.rho2d;
+    if (kForGrad) {
+        h.sx = h.on_splat ? h.sx : 0.f; h.sy = h.on_splat ? h.sy : 0.f; h.rz = h.on_splat ? h.rz : 0.f;
+        h.depth = fmaf(h.sy, s.Tw[1], fmaf(h.sx, s.Tw[0], s.Tw[2]));
+    } else {
+        h.depth = h.on_splat ? (h.sx * s.Tw[0] + h.sy * s.Tw[1]) + s.Tw[2] : s.Tw[2];
+    }
     // G = exp(-rho / 2) as one multiply and v_exp_f32: __expf(-0.5f * rho) is exp2 of
     // (-0.5f * rho) * log2(e), and halving is exact, so rho * (-log2(e) / 2) has the same bits
     h.G = __builtin_amdgcn_exp2f(rho * __uint_as_float(0xbf38aa3bu));
@@ -485,19 +499,20 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
             }
             const Splat s = unpack(q5);
             Hit h;
-            const bool c = eval_hit(s, fx, fy, h) & (pos < last);
+            const bool c = eval_hit<true>(s, fx, fy, h) & (pos < last);
             if (__ballot(c) == 0ull) continue;  // wave-uniform: nobody in the strip is touched
             // No divergent region below: every lane runs the same instructions and idle lanes
-            // are neutralised through a few selected roots (alpha, depth, G, sx, sy, rz = 0 or
-            // 1), which makes all of their 20 partial gradients exact zeros.  A branch here
-            // would cost more in phi copies and zero fills than the selects do.
-            const bool c3 = c & (h.rho3d <= h.rho2d);  // ray-splat intersection drives G
+            // are neutralised through two selected roots (alpha = 0, depth = 1): with them w,
+            // dL/dalpha and dL/ddepth are exact zeros, and every other factor (G, sx, sy, rz) is
+            // finite in every lane, so all 20 partial gradients of an idle lane are exact
+            // zeros.  A branch here would cost more in phi copies and zero fills.
+            const bool c3 = h.on_splat;                // ray-splat intersection drives G
             const float alpha = c ? h.alpha : 0.f;
             const float r_one_m = rcp_fast(1.f - alpha);  // exactly 1 for idle lanes
             T = T * r_one_m;
             const float w = alpha * T;
             const float depth = c ? h.depth : 1.f;
-            const float G = c ? h.G : 0.f;
+            const float G = h.G;                       // in [0, 1] in every lane
             // distortion weight of this splat (the per-pixel moments are final ones)
             const float rd = rcp_fast(depth);
             const float m = fmaf(rd, -c1 * kNearN, c1);       // c1 (1 - near / depth)
@@ -519,7 +534,7 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
             g[9] = G * dL_dalpha;      // dL/dopacity (slot 9)
             // (slots 12..19: formed in the reduction from the constants chosen above)
             const float a = -s.opa * g[9];             // dL/drho * -2, zero for idle lanes
-            const float sx = c3 ? h.sx : 0.f, sy = c3 ? h.sy : 0.f, rz = c3 ? h.rz : 0.f;
+            const float sx = h.sx, sy = h.sy, rz = h.rz;   // zeros off the splat (eval_hit<true>)
             const float dsx = a * sx + dL_dz * s.Tw[0];
             const float dsy = a * sy + dL_dz * s.Tw[1];
             const float dpx = dsx * rz, dpy = dsy * rz;  // rz = 0 switches the whole chain off
