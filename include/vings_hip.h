@@ -496,6 +496,12 @@ int vings_depth_refresh(int H, int W, const float* depth_sum, const float* alpha
                         float* dense_map, float* coarse_map, void* stream);
 int vings_splat_top3_update(int N, const float* cur_importance, int kf_id, float* scores3,
                             int32_t* kfids3, void* stream);
+/* The same, skipped as a whole on the device when *gate < gate_min: the reference drops a view
+ * whose render stays below 0.1 everywhere with a host-side test (loop/loop_model.py:181); with
+ * gate = the rgb_max word of vings_surfel_blend_importance the host never waits for it. */
+int vings_splat_top3_update_gated(int N, const float* cur_importance, int kf_id, float* scores3,
+                                  int32_t* kfids3, const float* gate, float gate_min,
+                                  void* stream);
 int vings_splat_reanchor(int N, float* xyz, float* rotation, const int32_t* owner_kf,
                          int owner_stride, int kf_start, int kf_end, int K, const float* old_w2c,
                          const float* new_c2w, const float* delta_quat, const float* scale,

@@ -118,6 +118,23 @@ def test_top3_update_matches_reference_logic():
                                              _lib.stream_ptr(torch.device(DEV))), "top3")
     np.testing.assert_array_equal(ts.cpu().numpy(), s)
     np.testing.assert_array_equal(tk.cpu().numpy(), k)
+    # the gated form: a view whose gate word lies below the threshold changes nothing, one at or
+    # above it is folded in like the plain call does (loop_model.py:181 decided on the device)
+    cur = rng.random(n).astype(np.float32)
+    tc = torch.from_numpy(cur).to(DEV)
+    gate = torch.tensor([0.05], device=DEV)
+    _lib.check(L.vings_splat_top3_update_gated(n, _lib.ptr(tc), 99, _lib.ptr(ts), _lib.ptr(tk),
+                                               _lib.ptr(gate), 0.1, _lib.stream_ptr(torch.device(DEV))),
+               "top3 gated")
+    np.testing.assert_array_equal(ts.cpu().numpy(), s)
+    np.testing.assert_array_equal(tk.cpu().numpy(), k)
+    gate.fill_(0.1)
+    _lib.check(L.vings_splat_top3_update_gated(n, _lib.ptr(tc), 99, _lib.ptr(ts), _lib.ptr(tk),
+                                               _lib.ptr(gate), 0.1, _lib.stream_ptr(torch.device(DEV))),
+               "top3 gated")
+    s, k = mo.top3_update(s, k, cur, 99)
+    np.testing.assert_array_equal(ts.cpu().numpy(), s)
+    np.testing.assert_array_equal(tk.cpu().numpy(), k)
 
 
 def test_calc_score_and_rectify_gaussians():

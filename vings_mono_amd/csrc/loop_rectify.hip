@@ -12,9 +12,12 @@ namespace vings {
 
 __global__ __launch_bounds__(256) void splat_top3_update_kernel(int N, const float* __restrict__ cur,
                                                                 int kf, float* __restrict__ scores3,
-                                                                int32_t* __restrict__ ids3) {
+                                                                int32_t* __restrict__ ids3,
+                                                                const float* __restrict__ gate,
+                                                                float gate_min) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
+    if (gate && *gate < gate_min) return;     // the whole view is skipped (decided on the device)
     const float c = cur[i];
     float s0 = scores3[3 * i], s1 = scores3[3 * i + 1], s2 = scores3[3 * i + 2];
     int k0 = ids3[3 * i], k1 = ids3[3 * i + 1], k2 = ids3[3 * i + 2];
@@ -101,7 +104,20 @@ extern "C" int vings_splat_top3_update(int N, const float* cur_importance, int k
     VINGS_REQUIRE(cur_importance && scores3 && kfids3, "null pointer");
     ProfScope prof(PROF_GLUE, (hipStream_t)stream);
     splat_top3_update_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(N, cur_importance, kf_id,
-                                                                            scores3, kfids3);
+                                                                            scores3, kfids3, nullptr, 0.f);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}
+
+extern "C" int vings_splat_top3_update_gated(int N, const float* cur_importance, int kf_id,
+                                             float* scores3, int32_t* kfids3, const float* gate,
+                                             float gate_min, void* stream) {
+    VINGS_REQUIRE(N >= 0, "sizes");
+    if (N == 0) return VINGS_OK;
+    VINGS_REQUIRE(cur_importance && scores3 && kfids3 && gate, "null pointer");
+    ProfScope prof(PROF_GLUE, (hipStream_t)stream);
+    splat_top3_update_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(N, cur_importance, kf_id,
+                                                                            scores3, kfids3, gate, gate_min);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }

@@ -243,11 +243,15 @@ def rectify_tracker(mapper, c2w_list, intr, dense_maps, coarse_maps):
     K, H, W = dense_maps.shape
     assert coarse_maps.shape == (K, H // 8, W // 8) and len(c2w_list) == K
     with torch.no_grad():
-        params = {k: v.detach() for k, v in mapper.params.items()}
+        # activations once for all K views; the lean blend pass (depth and alpha are all that is
+        # read here), its tiles taken longest list first
+        act = synth.activate({k: v.detach() for k, v in mapper.params.items()})
+        args = [act[k].contiguous() for k in ("means3D", "colors", "opacities", "scales", "rotations")]
         for k, c2w in enumerate(c2w_list):
             w2c = torch.linalg.inv(c2w.to(dev).float())
-            _, _, allmap = harness.render_raw(params, w2c, intr)
-            allmap = allmap.contiguous()
+            st, _ = surfel.rasterize_forward(*args, harness.view_settings(w2c, intr), keep_keys=False,
+                                             lean=True, order_tiles=True)
+            allmap = st.allmap
             _lib.check(L.vings_depth_refresh(H, W, _lib.ptr(allmap[0]), _lib.ptr(allmap[1]),
                                              _lib.ptr(dense_maps[k]), _lib.ptr(coarse_maps[k]),
                                              _lib.stream_ptr(dev)), "vings_depth_refresh")
@@ -303,11 +307,11 @@ def calc_score(mapper, c2w_list, kf_ids, intr):
             w2c = torch.linalg.inv(c2w.to(dev))
             surfel.view_importance(*args, view_settings(w2c, intr), out=cur, accumulate=False,
                                    rgb_max=rgb_max)
-            if float(rgb_max) < 0.1:      # the reference's own host-side test (loop_model.py:181)
-                continue
-            _lib.check(L.vings_splat_top3_update(n, _lib.ptr(cur), int(kf), _lib.ptr(scores3),
-                                                 _lib.ptr(ids3), _lib.stream_ptr(dev)),
-                       "vings_splat_top3_update")
+            # the reference's host-side test (loop_model.py:181), taken on the device: the host
+            # does not wait for the view's largest colour value
+            _lib.check(L.vings_splat_top3_update_gated(
+                n, _lib.ptr(cur), int(kf), _lib.ptr(scores3), _lib.ptr(ids3), _lib.ptr(rgb_max), 0.1,
+                _lib.stream_ptr(dev)), "vings_splat_top3_update_gated")
     return scores3, ids3
 
 

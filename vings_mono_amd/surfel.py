@@ -85,7 +85,7 @@ class thread_binning:
 
 
 def rasterize_forward(means3D, colors, opacities, scales, rotations, settings, keep_keys=False,
-                      raw=None, dgeom=None, lean=False):
+                      raw=None, dgeom=None, lean=False, order_tiles=None):
     """Run projection -> binning -> blend. Returns (SurfelForwardState, aux).
 
     `raw` = (raw_opacity, raw_scaling, raw_rotation): the stored parameters.  The projection
@@ -94,11 +94,13 @@ def rasterize_forward(means3D, colors, opacities, scales, rotations, settings, k
     ([N, GRAD_STRIDE] float32) may be handed over too: the projection zeroes the rows the
     backward pass will add into, and `blend_backward(..., dgeom=dgeom)` skips its own clearing.
     `lean`: the blend pass of the mapper's own view step, which leaves the median depth and the
-    flow planes at zero (vings_surfel_blend_forward_lean)."""
+    flow planes at zero (vings_surfel_blend_forward_lean).
+    `order_tiles`: the blend pass takes its tiles longest list first (default: whenever `dgeom`
+    is given, i.e. in the mapper's view step)."""
     if lean and settings.u2_minus_u1 is not None:
         raise _lib.VingsError("the lean blend passes carry no flow")
     return _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys, True, raw,
-                    dgeom, lean)
+                    dgeom, lean, order_tiles)
 
 
 def view_importance(means3D, colors, opacities, scales, rotations, settings, out=None,
@@ -127,7 +129,7 @@ _D_HINT = {}       # (device index, H, W) -> (instance count, depth key bits) of
 
 
 def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys, blend, raw=None,
-             dgeom=None, lean=False):
+             dgeom=None, lean=False, order_tiles=None):
     L = _lib.lib()
     dev = means3D.device
     N = means3D.shape[0]
@@ -184,7 +186,7 @@ def _forward(means3D, colors, opacities, scales, rotations, settings, keep_keys,
         st.allmap = torch.empty((AUX_CHANNELS, H, W), dtype=torch.float32, device=dev)
         st.final_T = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         st.n_contrib = torch.empty((2, H, W), dtype=torch.int32, device=dev)
-        if ORDER_TILES and dgeom is not None:
+        if ORDER_TILES and (dgeom is not None if order_tiles is None else order_tiles):
             # the mapper's view step: both blend passes take the tiles longest list first
             st.tile_order = torch.empty(T, dtype=torch.int32, device=dev)
             check(L.vings_surfel_tile_order(H, W, ptr(st.ranges), ptr(st.tile_order), stream),
