@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256, 7) void blend_fwd_kernel(
     // (tile_order: a permutation of the tiles, longest list first; without it the tiles are
     // handed out XCD-contiguously)
     const int tile = tile_order ? (int)tile_order[blockIdx.x] : xcd_contiguous(blockIdx.x, gridDim.x);
+    if ((unsigned)tile >= gridDim.x) return;   // a caller's order array with a stray entry
     const int tx = tile % gx, ty = tile / gx;
     // wave w renders block (w & 1, w >> 1) of the tile; lane l is pixel (l & 7, l >> 3) of it
     const int px = tx * 16 + kBlk * ((threadIdx.x >> 6) & 1) + (threadIdx.x & 7);
@@ -372,6 +373,7 @@ __global__ __launch_bounds__(256, 6) void blend_bwd_kernel(
     __shared__ unsigned long long hit[16];
     __shared__ uint32_t wmax[4];
     const int tile = tile_order ? (int)tile_order[blockIdx.x] : xcd_contiguous(blockIdx.x, gridDim.x);
+    if ((unsigned)tile >= gridDim.x) return;   // a caller's order array with a stray entry
     const int tx = tile % gx, ty = tile / gx;
     // wave w renders block (w & 1, w >> 1) of the tile; lane l is pixel (l & 7, l >> 3) of it
     const int px = tx * 16 + kBlk * ((threadIdx.x >> 6) & 1) + (threadIdx.x & 7);
