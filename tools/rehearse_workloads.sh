@@ -11,7 +11,7 @@ timeout -k 10 300 $TR --master-port 29801 bench.py --gpus 2 --rehearse-gloo --wo
 timeout -k 10 300 $TR --master-port 29802 bench.py --gpus 2 --rehearse-gloo --workload c5 --splats 500000 --loop-keyframes 8 --width 960 --height 544 $COMMON > $OUT/c5_n2.json 2> $OUT/c5_n2.err &&
 timeout -k 10 300 $TR --master-port 29803 bench.py --gpus 2 --rehearse-gloo --workload c3 --exchange planar --splats 200000 --width 960 --height 544 $COMMON > $OUT/c3_planar_n2.json 2> $OUT/c3_planar_n2.err
 r=$?
-for f in c4_n1 c4_n2 c5_n2 c3_planar_n2; do echo "== $f"; tail -c 700 $OUT/$f.json 2>/dev/null | python3 -c "
+for f in c4_n1 c4_n2 c5_n2 c3_planar_n2; do echo "== $f"; cat $OUT/$f.json 2>/dev/null | python3 -c "
 import sys,json
 try:
     d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(d['value'], d['n_gpus'], d['config']['workload'][:70], d['config'].get('exchange'))
