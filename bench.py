@@ -315,7 +315,7 @@ def main():
         barrier()
         return round(n_views_total * n_steps / (time.perf_counter() - t), 3)
 
-    reference_api = reference_binning = graph_replay = None
+    reference_api = reference_binning = graph_replay = autograd_api = None
     if args.rehearse_rccl:
         args.no_side_runs = True
     if world == 1 and not args.no_side_runs and not args.no_graph_run and loop is None \
@@ -328,6 +328,9 @@ def main():
         # GaussianRasterizer through autograd, the PyTorch loss graph, loss.backward(), PyTorch
         # score bookkeeping, SparseGaussianAdam.step -- through the drop-in names
         reference_api = side_run(autograd=True, torch_loss=True)
+        # the same loop with one call changed: the loss through harness.mapping_loss_fused (the
+        # fused HIP kernels behind a differentiable scalar) instead of the PyTorch loss graph
+        autograd_api = side_run(autograd=True, torch_loss=False)
         if args.binning == "tight":
             surfel.set_tight_binning(False)
             reference_binning = side_run()
@@ -405,6 +408,11 @@ def main():
                 "value": reference_api, "unit": "frames/s",
                 "what": "same step through GaussianRasterizer autograd + PyTorch loss graph + "
                         "PyTorch bookkeeping (the reference's call pattern, gaussian_base.py:367-403)"},
+            "autograd_api": None if autograd_api is None else {
+                "value": autograd_api, "unit": "frames/s",
+                "what": "the reference's call pattern with the loss taken from "
+                        "harness.mapping_loss_fused: GaussianRasterizer through autograd, "
+                        "loss.backward(), PyTorch score bookkeeping, SparseGaussianAdam.step"},
             "graph_replay": None if graph_replay is None else {
                 "value": graph_replay, "unit": "frames/s",
                 "what": "the same fused step with every view replayed from a HIP graph captured "

@@ -171,3 +171,19 @@ def test_mapper_step_matches_torch_graph():
         assert scale > 0
         err = float((ga[k] - gb[k]).abs().max())
         assert err <= 1e-3 * scale, f"{k}: {err:.3e} vs {scale:.3e}"
+
+
+def test_fused_loss_as_a_differentiable_scalar():
+    """harness.mapping_loss_fused: `loss.backward()` leaves on the rasteriser outputs the
+    gradient maps of mapping_loss_hip, scaled by whatever multiplies the loss upstream."""
+    dev = torch.device("cuda:0")
+    rgb, allmap, gt, w2c, intr = _inputs(75, 101, 31)
+    gt = {k: v.to(dev) for k, v in gt.items()}
+    r = rgb.to(dev).requires_grad_(True)
+    a = allmap.to(dev).requires_grad_(True)
+    vec, d_rgb, d_allmap = harness.mapping_loss_hip(r.detach(), a.detach(), gt, w2c[:3, :3], intr, WEIGHTS)
+    loss, loss_vec = harness.mapping_loss_fused(r, a, gt, w2c[:3, :3], intr, WEIGHTS)
+    assert loss.requires_grad and not loss_vec.requires_grad
+    assert torch.equal(loss_vec, vec) and float(loss.detach()) == float(vec[0])
+    (2.5 * loss).backward()
+    assert torch.equal(r.grad, d_rgb * 2.5) and torch.equal(a.grad, d_allmap * 2.5)

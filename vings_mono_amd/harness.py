@@ -195,6 +195,33 @@ def mapping_loss_hip(rgb, allmap, gt, Rw2c_host, intr, weights=DEFAULT_LOSS_WEIG
     return loss_vec, d_rgb, d_allmap
 
 
+class _MappingLossFunction(torch.autograd.Function):
+    """`mapping_loss_hip` as a differentiable scalar: forward runs the fused kernels and keeps
+    the two gradient maps, backward scales them by the upstream gradient."""
+
+    @staticmethod
+    def forward(ctx, rgb, allmap, gt, Rw2c_host, intr, weights, cache):
+        loss_vec, d_rgb, d_allmap = mapping_loss_hip(rgb.detach(), allmap.detach(), gt, Rw2c_host,
+                                                     intr, weights, cache=cache)
+        ctx.save_for_backward(d_rgb, d_allmap)
+        ctx.mark_non_differentiable(loss_vec)
+        return loss_vec[0].clone(), loss_vec
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_vec):
+        d_rgb, d_allmap = ctx.saved_tensors
+        return d_rgb * g_loss, d_allmap * g_loss, None, None, None, None, None
+
+
+def mapping_loss_fused(rgb, allmap, gt, Rw2c_host, intr, weights=DEFAULT_LOSS_WEIGHTS, cache=False):
+    """The mapping loss of a rendered view as a scalar tensor that `backward()` can be called
+    on, computed by the fused HIP kernels: for a training loop written like the reference's
+    (gaussian_base.py:367-382: render, `get_loss`, `loss.backward()`) that keeps the
+    rasteriser's raw outputs `rgb` [3,H,W] and `allmap` [9,H,W].  Returns (loss, loss_vec):
+    loss_vec [8] holds total, rgb, normal, alpha, depth, dist terms and the two pixel counts."""
+    return _MappingLossFunction.apply(rgb, allmap, gt, Rw2c_host, intr, weights, cache)
+
+
 def score_weight(current_scores, global_scores):
     """Per-splat gradient weight s0 / (S0 + 1e-6 + s0), [N,1]."""
     s0 = current_scores[:, 0]
@@ -244,9 +271,8 @@ class SurfelMapper:
         rgb, radii, allmap = render_raw(self.params, w2c, intr, scores=scores)
         if Rw2c_host is None:
             Rw2c_host = w2c[:3, :3].cpu()
-        loss_vec, d_rgb, d_allmap = mapping_loss_hip(rgb.detach(), allmap.detach(), gt, Rw2c_host,
-                                                     intr, self.loss_weights)
-        torch.autograd.backward([rgb, allmap], [d_rgb, d_allmap])
+        loss, loss_vec = mapping_loss_fused(rgb, allmap, gt, Rw2c_host, intr, self.loss_weights)
+        loss.backward()
         self.last_loss = loss_vec[0]
         self.last_loss_terms = loss_vec
         return radii, scores.grad.detach()
