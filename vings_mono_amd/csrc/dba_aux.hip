@@ -302,13 +302,14 @@ __global__ __launch_bounds__(256) void altcorr_fwd_kernel(
 }
 
 // Tiled form (r <= 3, C a multiple of 16): a workgroup takes a 16x4 block of query pixels of one
-// (b, s), a wave one row of it, a lane one integer position of the (2r+2)^2 neighbourhood, for
-// all 16 pixels of the row at once (16 accumulators).  The targets of neighbouring pixels land
-// close to each other (a tracker's flow field is smooth), so their neighbourhoods overlap: the
-// workgroup takes the bounding rectangle of all of them inside fmap2 and, when it holds at most
-// kAltCap positions, passes it through LDS in chunks of 16 channels -- every fmap2 row is then
-// fetched once per workgroup with full-line loads instead of once per pixel by a lane of its
-// own.  Scattered targets (rectangle too large) read the rows from global memory as before.
+// (b, s), a wave one row of it.  The wave handles four pixels at a time, 16 lanes each, a lane a
+// 2x2 patch of integer positions of the pixel's (2r+2)^2 neighbourhood (16 accumulators: four
+// steps x four positions).  The targets of neighbouring pixels land close to each other (a
+// tracker's flow field is smooth), so their neighbourhoods overlap: the workgroup takes the
+// bounding rectangle of all of them inside fmap2 and, when it holds at most kAltCap positions,
+// passes it through LDS in chunks of 16 channels -- every fmap2 row is then fetched once per
+// workgroup with full-line loads instead of once per pixel by a lane of its own.  Scattered
+// targets (rectangle too large) read the rows from global memory as before.
 constexpr int kAltTW = 16, kAltTH = 4, kAltTile = kAltTW * kAltTH;
 constexpr int kAltCap = 512;      // fmap2 positions a workgroup stages
 constexpr int kAltCh = 16;        // channels per staged chunk
@@ -316,24 +317,33 @@ constexpr int kAltStride = 20;    // floats per staged position: 16 + 4 (16-byte
                                   // lanes of a 16-lane group fall into different banks)
 constexpr int kAltStageIters = kAltCap * (kAltCh / 4) / 256;
 constexpr size_t kAltTileLds =
-    sizeof(float) * (kAltCap * kAltStride + kAltTile * kAltCh + 4 * 64 + 4 * kAltTile + 4);
+    sizeof(float) * (kAltCap * kAltStride + kAltTile * kAltCh + 4 * 4 * 64 + 4 * kAltTile + 4);
 
+// One step = four pixels of the wave's row (16 lanes each), a lane a 2x2 patch of positions:
+// the pixel's 16 fmap1 values are read once for four dot products (20 LDS reads of 16 bytes per
+// 64 multiply-adds of a lane instead of 32; the loop is bound by exactly these reads).
 template <bool kStaged>
 __device__ __forceinline__ void altcorr_row_dots(float (&acc)[kAltTW], const int (&off)[kAltTW],
-                                                 const float* __restrict__ f1row,
+                                                 const float* __restrict__ f1lane,
                                                  const float* __restrict__ src) {
 #pragma unroll
-    for (int p = 0; p < kAltTW; ++p) {
-        const int o = off[p];
-        const float4* a4 = reinterpret_cast<const float4*>(f1row + p * kAltCh);
-        const float4* u4 = reinterpret_cast<const float4*>(src + (o < 0 ? 0 : o));
-        float d = 0.f;
+    for (int st = 0; st < kAltTW / 4; ++st) {
+        const float4* a4 = reinterpret_cast<const float4*>(f1lane + st * 4 * kAltCh);
+        float4 v[kAltCh / 4];
 #pragma unroll
-        for (int c = 0; c < kAltCh / 4; ++c) {
-            const float4 u = u4[c], v = a4[c];
-            d += u.x * v.x; d += u.y * v.y; d += u.z * v.z; d += u.w * v.w;
+        for (int c = 0; c < kAltCh / 4; ++c) v[c] = a4[c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int o = off[st * 4 + e];
+            const float4* u4 = reinterpret_cast<const float4*>(src + (o < 0 ? 0 : o));
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < kAltCh / 4; ++c) {
+                const float4 u = u4[c];
+                d += u.x * v[c].x; d += u.y * v[c].y; d += u.z * v[c].z; d += u.w * v[c].w;
+            }
+            acc[st * 4 + e] += o < 0 ? 0.f : d;
         }
-        acc[p] += o < 0 ? 0.f : d;
     }
 }
 
@@ -344,13 +354,13 @@ __global__ __launch_bounds__(256) void altcorr_fwd_tile_kernel(
     extern __shared__ float alt_lds[];
     float* reg = alt_lds;                                  // [kAltCap][kAltStride]; at the end [K][64]
     float* f1s = reg + kAltCap * kAltStride;               // [64 pixels][16 channels]
-    float* dots = f1s + kAltTile * kAltCh;                 // [4 waves][64]
-    int* ix0 = reinterpret_cast<int*>(dots + 4 * 64);      // [64] window origin of every pixel
+    float* dots = f1s + kAltTile * kAltCh;                 // [4 waves][4 pixels][64]
+    int* ix0 = reinterpret_cast<int*>(dots + 4 * 4 * 64);  // [64] window origin of every pixel
     int* iy0 = ix0 + kAltTile;
     float* fdx = reinterpret_cast<float*>(iy0 + kAltTile);
     float* fdy = fdx + kAltTile;
     int* red = reinterpret_cast<int*>(fdy + kAltTile);     // rectangle: x0, y0, width, height
-    const int n1 = 2 * r + 2, P = n1 * n1, rd = 2 * r + 1, K = rd * rd;
+    const int n1 = 2 * r + 2, rd = 2 * r + 1, K = rd * rd;
     const int tiles_x = (W + kAltTW - 1) / kAltTW, tiles_y = (H + kAltTH - 1) / kAltTH;
     int blk = blockIdx.x;
     const int tx = blk % tiles_x; blk /= tiles_x;
@@ -395,16 +405,22 @@ __global__ __launch_bounds__(256) void altcorr_fwd_tile_kernel(
     const bool any = rw > 0 && rh > 0;
     const bool staged = any && npos <= kAltCap;
 
-    // where this lane's position of every pixel of the wave's row lives (-1: outside fmap2)
+    // Lane -> (pixel of a step, 2x2 patch of the neighbourhood): ps = lane / 16 is the pixel
+    // among the four of a step, the low four bits number the (n1/2)^2 patches.  off[4 st + e]:
+    // where element e of the patch lives for the pixel of step st (-1: outside fmap2 or no patch).
+    const int ps = lane >> 4, q16 = lane & 15, half = n1 >> 1;
+    const int py2 = q16 / half, px2 = q16 - py2 * half;
     int off[kAltTW];
-    {
-        const int iy = lane / n1, ix = lane - iy * n1;
 #pragma unroll
-        for (int p = 0; p < kAltTW; ++p) {
-            const int yy = iy0[wv * kAltTW + p] + iy, xx = ix0[wv * kAltTW + p] + ix;
-            const bool ok = lane < P && yy >= 0 && yy < H2 && xx >= 0 && xx < W2;
-            off[p] = !ok ? -1 : staged ? ((yy - ry0) * rw + (xx - rx0)) * kAltStride
-                                       : (yy * W2 + xx) * C;
+    for (int st = 0; st < kAltTW / 4; ++st) {
+        const int pi = wv * kAltTW + st * 4 + ps;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int iy = 2 * py2 + (e >> 1), ix = 2 * px2 + (e & 1);
+            const int yy = iy0[pi] + iy, xx = ix0[pi] + ix;
+            const bool ok = q16 < half * half && yy >= 0 && yy < H2 && xx >= 0 && xx < W2;
+            off[st * 4 + e] = !ok ? -1 : staged ? ((yy - ry0) * rw + (xx - rx0)) * kAltStride
+                                                : (yy * W2 + xx) * C;
         }
     }
     // what this thread copies into LDS per chunk (the rectangle does not move between chunks)
@@ -442,23 +458,29 @@ __global__ __launch_bounds__(256) void altcorr_fwd_tile_kernel(
         *reinterpret_cast<float4*>(f1s + threadIdx.x * 4) =
             f1src ? *reinterpret_cast<const float4*>(f1src + ch * kAltCh) : make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
-        if (staged) altcorr_row_dots<true>(acc, off, f1s + wv * kAltTW * kAltCh, reg);
-        else altcorr_row_dots<false>(acc, off, f1s + wv * kAltTW * kAltCh, fmap2b + ch * kAltCh);
+        if (staged) altcorr_row_dots<true>(acc, off, f1s + (wv * kAltTW + ps) * kAltCh, reg);
+        else altcorr_row_dots<false>(acc, off, f1s + (wv * kAltTW + ps) * kAltCh, fmap2b + ch * kAltCh);
     }
     __syncthreads();                           // reg becomes the output tile [K][64]
     float* tile = reg;
 #pragma unroll
-    for (int p = 0; p < kAltTW; ++p) {
-        dots[wv * 64 + lane] = acc[p];
+    for (int st = 0; st < kAltTW / 4; ++st) {
+        float* d4 = dots + wv * 4 * 64;               // this wave's [4 pixels][64 positions]
+        if (q16 < half * half) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                d4[ps * 64 + (2 * py2 + (e >> 1)) * n1 + 2 * px2 + (e & 1)] = acc[st * 4 + e];
+        }
         // same wave wrote and reads: LDS operations of a wave complete in order
         __builtin_amdgcn_wave_barrier();
-        const int pi = wv * kAltTW + p;
-        const float dx = fdx[pi], dy = fdy[pi];
-        if (lane < K) {
-            const int i = lane / rd, j = lane - i * rd;
-            const float* e = dots + wv * 64 + i * n1 + j;
-            tile[lane * kAltTile + pi] = (1.f - dx) * (1.f - dy) * e[0] + dx * (1.f - dy) * e[1] +
-                                         (1.f - dx) * dy * e[n1] + dx * dy * e[n1 + 1];
+        for (int o = lane; o < 4 * K; o += 64) {      // the 4 K window values of the step's pixels
+            const int sub = o / K, k = o - sub * K;
+            const int pi = wv * kAltTW + st * 4 + sub;
+            const float dx = fdx[pi], dy = fdy[pi];
+            const int i = k / rd, j = k - i * rd;
+            const float* e = d4 + sub * 64 + i * n1 + j;
+            tile[k * kAltTile + pi] = (1.f - dx) * (1.f - dy) * e[0] + dx * (1.f - dy) * e[1] +
+                                      (1.f - dx) * dy * e[n1] + dx * dy * e[n1 + 1];
         }
         __builtin_amdgcn_wave_barrier();
     }
