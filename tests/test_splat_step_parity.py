@@ -373,3 +373,39 @@ def test_projection_with_inline_activation_equals_activate_then_project():
                 a, b = a[vis], b[vis]
             assert torch.equal(a, b), name
         assert torch.equal(want.keys[:want.D], got.keys[:got.D])
+
+
+def test_fused_view_with_nothing_in_view_changes_nothing():
+    """A view step whose camera looks away from every splat (no instance, empty tile lists, the
+    ordered blend passes walking 0-length lists): finite loss, parameters, Adam moments and
+    score records untouched, and the next ordinary step still works (eager and as a graph
+    candidate alike: the empty step must not poison the instance-count hint)."""
+    dev = torch.device(DEV)
+    W, H = 160, 96
+    raw = synth.make_splats(3000, W, H, n_views=2, seed=27)
+    intr = synth.intrinsic_for(W, H)
+    c2w = synth.window_poses(2)
+    gtp = {k: v.to(dev) for k, v in synth.perturb_splats(raw).items()}
+    w2c = torch.linalg.inv(c2w[0]).to(dev)
+    with torch.no_grad():
+        pr = harness.render(gtp, w2c, intr)
+    gt = {"rgb": pr["rgb"].clone(), "depth": pr["depth"].clone(), "depth_cov": torch.ones_like(pr["depth"])}
+    m = harness.SurfelMapper(raw, dev)
+    m.fused_view(harness.view_settings(w2c, intr), intr, gt, w2c[:3, :3].cpu(), 0)   # an ordinary step
+    torch.cuda.synchronize()
+    before = {k: m.params[k].detach().clone() for k in m.NAMES}
+    mom = {k: m.optimizer.state[m.params[k]]["exp_avg"].clone() for k in m.NAMES}
+    rec = (m.global_scores.clone(), m.local_scores.clone(), m.globalkf_id.clone())
+    away = torch.diag(torch.tensor([-1.0, 1.0, -1.0, 1.0], device=dev)) @ w2c
+    vec = m.fused_view(harness.view_settings(away, intr), intr, gt, away[:3, :3].cpu(), 1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(vec).all() and m.last_stats()["D"] == 0
+    for k in m.NAMES:
+        assert torch.equal(m.params[k].detach(), before[k]), k
+        assert torch.equal(m.optimizer.state[m.params[k]]["exp_avg"], mom[k]), k
+    assert torch.equal(m.global_scores, rec[0]) and torch.equal(m.local_scores, rec[1])
+    assert torch.equal(m.globalkf_id, rec[2])
+    m.fused_view(harness.view_settings(w2c, intr), intr, gt, w2c[:3, :3].cpu(), 0)
+    torch.cuda.synchronize()
+    assert m.last_stats()["D"] > 0
+    assert not torch.equal(m.params["_xyz"].detach(), before["_xyz"])
