@@ -313,7 +313,8 @@ int vings_surfel_blend_backward_accumulate_lean(
  * in that order (workgroup b renders tile tile_order[b]; NULL = the default XCD-contiguous
  * order), so a launch ends on its cheapest tiles and the workgroups dealt round-robin over the
  * XCDs carry similar loads.  Outputs have the bits of the unordered passes (the gradient rows up
- * to the order of their float atomics, as before).  `lean` != 0 selects the lean passes above;
+ * to the order of their float atomics, as before; vings_surfel_blend_importance_ordered is
+ * vings_surfel_blend_importance with that argument).  `lean` != 0 selects the lean passes above;
  * the backward adds into dgeom like vings_surfel_blend_backward_accumulate.  tile_order must be
  * a permutation of 0..T-1: a tile missing from it is not rendered. */
 int vings_surfel_tile_order(int H, int W, const uint32_t* ranges, uint32_t* tile_order,
@@ -329,6 +330,11 @@ int vings_surfel_blend_backward_accumulate_ordered(
     const float* geom, const float* bg, const uint8_t* pixel_mask, const float* final_T,
     const uint32_t* n_contrib, const float* dL_dcolor, const float* dL_dallmap, float* dgeom,
     const uint32_t* tile_order, void* stream);
+int vings_surfel_blend_importance_ordered(int N, int H, int W, const uint32_t* ranges,
+                                          const uint32_t* vals_sorted, const float* geom,
+                                          const uint8_t* pixel_mask, float* importance,
+                                          int accumulate, const float* bg, float* rgb_max,
+                                          const uint32_t* tile_order, void* stream);
 
 /* ------------------------------------------------------------------------
  * The view step under HIP stream capture (one graph per keyframe of the window, replayed every

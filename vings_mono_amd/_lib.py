@@ -55,6 +55,8 @@ _SIGNATURES = {
     "vings_splat_grad_finish": (_c.c_int, [_c.c_int] + [_P] * 15 + [_c.c_int64, _c.c_int] + [_P] * 7),
     "vings_surfel_blend_importance": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int] + [_P] * 5 +
                                       [_c.c_int, _P, _P, _P]),
+    "vings_surfel_blend_importance_ordered": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int] + [_P] * 5 +
+                                              [_c.c_int, _P, _P, _P, _P]),
     "vings_splat_compact_workspace_bytes": (_c.c_size_t, [_c.c_int]),
     "vings_splat_compact_plan": (_c.c_int, [_c.c_int, _P, _P, _P, _c.c_size_t,
                                             _c.POINTER(_c.c_int64), _P]),

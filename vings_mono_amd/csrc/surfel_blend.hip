@@ -282,13 +282,14 @@ __global__ __launch_bounds__(256, 6) void blend_importance_kernel(
     int H, int W, int gx, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ vals,
     const float* __restrict__ geom, const uint8_t* __restrict__ pixel_mask,
     float* __restrict__ importance, const float* __restrict__ bg,
-    uint32_t* __restrict__ rgb_max_bits) {
+    uint32_t* __restrict__ rgb_max_bits, const uint32_t* __restrict__ tile_order) {
     __shared__ float4 rec[kBatch * (kRec4 - 1)];
     __shared__ unsigned long long hit[16];
     __shared__ float acc[kBatch];
     __shared__ uint32_t ids[kBatch];
     __shared__ uint32_t wmaxs[4];
-    const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : xcd_contiguous(blockIdx.x, gridDim.x);
+    if ((unsigned)tile >= gridDim.x) return;   // a caller's order array with a stray entry
     const int tx = tile % gx, ty = tile / gx;
     const int px = tx * 16 + kBlk * ((threadIdx.x >> 6) & 1) + (threadIdx.x & 7);
     const int py = ty * 16 + kBlk * (threadIdx.x >> 7) + ((threadIdx.x >> 3) & 7);
@@ -700,11 +701,11 @@ static int blend_backward_impl(bool clear, bool lean, int N, int H, int W, const
     return VINGS_OK;
 }
 
-extern "C" int vings_surfel_blend_importance(int N, int H, int W, const uint32_t* ranges,
-                                             const uint32_t* vals_sorted, const float* geom,
-                                             const uint8_t* pixel_mask, float* importance,
-                                             int accumulate, const float* bg, float* rgb_max,
-                                             void* stream) {
+static int blend_importance_impl(int N, int H, int W, const uint32_t* ranges,
+                                 const uint32_t* vals_sorted, const float* geom,
+                                 const uint8_t* pixel_mask, float* importance, int accumulate,
+                                 const float* bg, float* rgb_max, const uint32_t* tile_order,
+                                 void* stream) {
     VINGS_REQUIRE(N >= 0 && H > 0 && W > 0, "sizes");
     if (N == 0) return VINGS_OK;
     VINGS_REQUIRE(ranges && importance, "null pointer");
@@ -717,9 +718,27 @@ extern "C" int vings_surfel_blend_importance(int N, int H, int W, const uint32_t
     ProfScope prof(PROF_BLEND_FWD, s);
     blend_importance_kernel<<<gx * gy, 256, 0, s>>>(H, W, gx, ranges, vals_sorted, geom,
                                                     pixel_mask, importance, bg,
-                                                    reinterpret_cast<uint32_t*>(rgb_max));
+                                                    reinterpret_cast<uint32_t*>(rgb_max), tile_order);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
+}
+
+extern "C" int vings_surfel_blend_importance(int N, int H, int W, const uint32_t* ranges,
+                                             const uint32_t* vals_sorted, const float* geom,
+                                             const uint8_t* pixel_mask, float* importance,
+                                             int accumulate, const float* bg, float* rgb_max,
+                                             void* stream) {
+    return blend_importance_impl(N, H, W, ranges, vals_sorted, geom, pixel_mask, importance,
+                                 accumulate, bg, rgb_max, nullptr, stream);
+}
+
+extern "C" int vings_surfel_blend_importance_ordered(int N, int H, int W, const uint32_t* ranges,
+                                                     const uint32_t* vals_sorted, const float* geom,
+                                                     const uint8_t* pixel_mask, float* importance,
+                                                     int accumulate, const float* bg, float* rgb_max,
+                                                     const uint32_t* tile_order, void* stream) {
+    return blend_importance_impl(N, H, W, ranges, vals_sorted, geom, pixel_mask, importance,
+                                 accumulate, bg, rgb_max, tile_order, stream);
 }
 
 extern "C" int vings_surfel_blend_backward(int N, int H, int W, const uint32_t* ranges,

@@ -116,10 +116,15 @@ def view_importance(means3D, colors, opacities, scales, rotations, settings, out
         out = torch.empty(N, dtype=torch.float32, device=means3D.device)
         accumulate = False
     mask = aux[3]
-    check(L.vings_surfel_blend_importance(N, st.H, st.W, ptr(st.ranges), ptr(st.vals), ptr(st.geom),
-                                          ptr(mask), ptr(out), 1 if accumulate else 0,
-                                          ptr(aux[2]), ptr(rgb_max), stream_ptr(means3D.device)),
-          "vings_surfel_blend_importance")
+    order = None
+    if ORDER_TILES and N > 0:
+        order = torch.empty(st.ranges.shape[0], dtype=torch.int32, device=means3D.device)
+        check(L.vings_surfel_tile_order(st.H, st.W, ptr(st.ranges), ptr(order),
+                                        stream_ptr(means3D.device)), "vings_surfel_tile_order")
+    check(L.vings_surfel_blend_importance_ordered(
+        N, st.H, st.W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(mask), ptr(out),
+        1 if accumulate else 0, ptr(aux[2]), ptr(rgb_max), ptr(order), stream_ptr(means3D.device)),
+        "vings_surfel_blend_importance_ordered")
     return out, st.radii
 
 
