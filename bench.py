@@ -30,8 +30,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", choices=("auto", "c3", "c4", "c5"), default="auto",
                     help="BASELINE config: c3 = 8-keyframe window + DBA on every GPU (the one the "
                          "metric is quoted on); c4 = one 32-keyframe window whose keyframes are "
@@ -322,7 +322,7 @@ def main():
             and not (args.autograd or args.torch_loss):
         step(graphed=True)          # eager: learns the instance counts
         step(graphed=True)          # captures one graph per keyframe
-        graph_replay = side_run(n_steps=args.steps, graphed=True)
+        graph_replay = side_run(n_steps=min(args.steps, 10), graphed=True)
     if world == 1 and not args.no_side_runs and not (args.autograd or args.torch_loss) and loop is None:
         # the reference's own call pattern (gaussian_base.py:367-403): PyTorch activations,
         # GaussianRasterizer through autograd, the PyTorch loss graph, loss.backward(), PyTorch
