@@ -25,7 +25,7 @@ bool trace_sync() {
 }
 }  // namespace vings
 
-extern "C" int vings_abi_version(void) { return 3; }
+extern "C" int vings_abi_version(void) { return 4; }   // 4: record layout {Tu,x}{Tv,y}{Tw,n0}.., ordered passes
 
 // ---------------------------------------------------------------------------
 // Per-kernel timing with HIP events recorded on the caller's stream.
