@@ -12,7 +12,7 @@ SHORT="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-dba --no-side-runs"
 
 timeout -k 10 400 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err &&
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- \
-    python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-side-runs > $OUT/bench_under_rocprof.json 2> $OUT/trace.err &&
+    python3 bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-side-runs > $OUT/bench_under_rocprof.json 2> $OUT/trace.err &&
 cp "$(ls $OUT/trace/*/*kernel_stats.csv | head -1)" $OUT/bench_kernel_stats.csv &&
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $SHORT > /dev/null 2> $OUT/pmc_fetch.err &&
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $SHORT > /dev/null 2> $OUT/pmc_write.err &&
