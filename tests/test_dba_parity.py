@@ -353,3 +353,37 @@ def test_altcorr_equals_volume_lookup_on_the_gpu():
     vol = torch.einsum("bhwc,byxc->bhwyx", t1, t2).contiguous()
     ref, = dba.corr_index_forward(vol, tc[:, 0].permute(0, 3, 1, 2).contiguous(), 3)
     assert rel(alt[:, 0].cpu().numpy(), ref.reshape(4, 49, 24, 32).cpu().numpy().astype(np.float64)) < 1e-5
+
+
+def test_altcorr_full_grid_properties():
+    """The 1080p / 8 tracker grid with 12 edges and a smooth flow field (the size at which no
+    all-pairs volume exists and the oracle takes minutes): the window is linear in either
+    feature map, and translating the second map together with the targets by whole pixels
+    leaves every window value that stays inside both maps unchanged."""
+    from vings_mono_amd import dba
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(17)
+    E, H, W, C, r = 12, 135, 240, 128, 3
+    f1 = (torch.randn(E, H, W, C, generator=g) / 4).to(dev)
+    f2 = (torch.randn(E, H, W, C, generator=g) / 4).to(dev)
+    h2 = (torch.randn(E, H, W, C, generator=g) / 4).to(dev)
+    xy = torch.stack(torch.meshgrid(torch.arange(W, dtype=torch.float32),
+                                    torch.arange(H, dtype=torch.float32), indexing="xy"), -1)
+    xy = xy[None, None].repeat(E, 1, 1, 1, 1) + (torch.rand(E, 1, 1, 1, 2, generator=g) - 0.5) * 20
+    xy = (xy + torch.randn(xy.shape, generator=g) * 0.5).to(dev).contiguous()
+    a, = dba.altcorr_forward(f1, f2, xy, r)
+    b, = dba.altcorr_forward(f1, h2, xy, r)
+    c, = dba.altcorr_forward(f1, 0.75 * f2 - 1.5 * h2, xy, r)
+    want = 0.75 * a - 1.5 * b
+    assert float((c - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    d, = dba.altcorr_forward(2.0 * f1, f2, xy, r)
+    assert torch.equal(d, 2.0 * a)                        # scaling by two is exact in float32
+    # shift the second map 5 right, 3 down (zero fill) and the targets with it
+    sh = torch.zeros_like(f2)
+    sh[:, 3:, 5:] = f2[:, :-3, :-5]
+    e, = dba.altcorr_forward(f1, sh, xy + torch.tensor([5.0, 3.0], device=dev), r)
+    x0 = torch.floor(xy[..., 0]) - r
+    y0 = torch.floor(xy[..., 1]) - r
+    inside = ((x0 >= 0) & (x0 + 2 * r + 1 < W - 5) & (y0 >= 0) & (y0 + 2 * r + 1 < H - 3))[:, :, None]
+    assert float(inside.float().mean()) > 0.7
+    assert float(((e - a).abs() * inside).max()) <= 2e-5 * float(a.abs().max())
