@@ -1,16 +1,20 @@
 // Tile binning for the surfel rasteriser on gfx950: every (splat, tile) instance of a view
 // into the list of its tile, every list ordered by depth.  Two levels:
-//   1. emit      keys (tile << 32 | float bits of depth) and splat indices, in splat order
+//   1. emit      (tile, splat index) pairs as two 32-bit arrays, in splat order
 //   2. tile sort stable least-significant-digit radix passes (8-bit digits, written for 64-lane
-//                wavefronts) over the TILE bits only: 2 passes at 1080p (13 tile bits) where
-//                sorting the whole (tile, depth) key took 5 over its 40 differing bits
-//   3. ranges    per-tile ranges from the tile-ordered keys
-//   4. depth sort one workgroup per tile orders its list in LDS by (depth bits, splat index):
+//                wavefronts) over the TILE numbers only: 2 passes at 1080p (13 tile bits) where
+//                sorting the whole (tile, depth) key took 5 over its 40 differing bits.  The
+//                depth does not travel through the passes (8 bytes per instance and pass
+//                direction instead of 12): the last stage fetches it by splat index
+//   3. ranges    per-tile ranges from the tile-ordered pairs
+//   4. depth sort one workgroup per tile gathers the depths of its list, orders it in LDS by
+//                (depth bits, splat index) and writes the keys (tile << 32 | depth bits) and
+//                values of the caller's arrays:
 //                a sample sort (bisection over 64 ordered sample keys, LDS counters, rank
 //                among the few bucket mates), a bitonic network below 129 entries and for the
 //                sample; lists beyond the LDS capacity: LDS-sorted runs + merge passes through
 //                the free half of the radix sort's ping-pong buffers
-// 9 launches instead of 17; 0.146 ms instead of 0.25 ms for the 2.4 M instances of a 1080p view.
+// 9 launches instead of 17 for the 2.4 M instances of a 1080p view.
 //
 // The order is fully determined: a splat emits at most one instance per tile and instances
 // are emitted in splat order, so a stable sort by (tile, depth) equals ordering every tile's
@@ -43,16 +47,15 @@ constexpr int kSortCap = 1024;          // composites one LDS depth sort holds (
 // exclusive prefix of tiles_touched, rebuilt here from the per-block prefix.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void emit_keys_kernel(
-    int N, int gx, const float* __restrict__ depth, const int32_t* __restrict__ rect,
+    int N, int gx, const int32_t* __restrict__ rect,
     const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_prefix,
-    uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ ranges,
+    uint32_t* __restrict__ tkeys, uint32_t* __restrict__ vals, uint32_t* __restrict__ ranges,
     int n_range_words, uint32_t cap) {
     // nothing is written beyond the `cap` entries the buffers hold (a speculative launch may
     // have guessed the instance count too small)
     __shared__ uint32_t wtot[4];
     __shared__ uint32_t start[257];     // first output slot of each splat, relative to the block
     __shared__ int4 srect[256];
-    __shared__ uint32_t sdepth[256];
     const int i = blockIdx.x * 256 + threadIdx.x;
     // tiles without instances keep the empty range [0,0): cleared here, ahead of
     // tile_ranges_kernel on the same stream, instead of by a separate fill command
@@ -66,10 +69,7 @@ __global__ __launch_bounds__(256) void emit_keys_kernel(
     for (int k = 0; k < w; ++k) off += wtot[k];
     start[threadIdx.x] = off;
     if (threadIdx.x == 255) start[256] = off + cnt;
-    if (cnt) {
-        srect[threadIdx.x] = reinterpret_cast<const int4*>(rect)[i];
-        sdepth[threadIdx.x] = __float_as_uint(depth[i]);
-    }
+    if (cnt) srect[threadIdx.x] = reinterpret_cast<const int4*>(rect)[i];
     __syncthreads();
     // The block's instances form one contiguous output range; lanes take consecutive slots
     // (coalesced stores) and look up the owning splat by bisection over the 256 starts.
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void emit_keys_kernel(
             const uint32_t row = idx / wd;
             tile = (uint32_t)(r.y + (int)row) * gx + (uint32_t)r.x + (idx - row * wd);
         }
-        keys[out0 + q] = ((uint64_t)tile << 32) | (uint64_t)sdepth[lo];
+        tkeys[out0 + q] = tile;
         vals[out0 + q] = (uint32_t)(blockIdx.x * 256 + lo);
     }
 }
@@ -105,13 +105,13 @@ __global__ __launch_bounds__(256) void emit_keys_kernel(
 // ---------------------------------------------------------------------------
 // radix sort
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t digit_of(uint64_t k, int shift) {
-    return (uint32_t)(k >> shift) & (kRadix - 1);
+__device__ __forceinline__ uint32_t digit_of(uint32_t k, int shift) {
+    return (k >> shift) & (kRadix - 1);
 }
 
 // Per-tile digit histogram of one pass: thist[digit][tile].
 __global__ __launch_bounds__(kSortThreads) void sort_tile_hist_kernel(
-    const uint64_t* __restrict__ keys, int64_t D, int shift, int ntiles,
+    const uint32_t* __restrict__ keys, int64_t D, int shift, int ntiles,
     uint32_t* __restrict__ thist, const uint32_t* __restrict__ tail) {
     __shared__ uint32_t h[kRadix];
     if (tail) D = min(D, (int64_t)tail[2]);
@@ -172,16 +172,18 @@ __global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t* __restrict__ t
 // round the rank of a key among equal digits is the number of lower lanes
 // holding the same digit, found with one ballot per digit bit.
 __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(
-    const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t D, int shift,
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t D, int shift,
     int ntiles, const uint32_t* __restrict__ thist, const uint32_t* __restrict__ totals,
-    const uint32_t* __restrict__ tail) {
+    const uint32_t* __restrict__ tail, int nbits) {
+    // nbits: significant bits of this pass's digit (the last pass of a 13-bit tile number has 5:
+    // the ballots of the bits above are all-zero and skipped)
     __shared__ uint32_t wcount[4][kRadix];  // per-wave digit counts, then prefixes
     if (tail) D = min(D, (int64_t)tail[2]);
     __shared__ uint32_t gbase[kRadix];
     __shared__ uint32_t tile_off[kRadix];
     __shared__ uint32_t wsum4[4];
-    __shared__ uint64_t lkey[kSortTile];
+    __shared__ uint32_t lkey[kSortTile];
     __shared__ uint32_t lval[kSortTile];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int k = threadIdx.x; k < 4 * kRadix; k += kSortThreads) (&wcount[0][0])[k] = 0;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(
     __syncthreads();
 
     const int64_t wbase = (int64_t)blockIdx.x * kSortTile + w * (kSortItems * 64);
-    uint64_t key[kSortItems];
+    uint32_t key[kSortItems];
     uint32_t val[kSortItems];
     uint32_t rank[kSortItems];
     const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
@@ -206,14 +208,16 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(
     for (int r = 0; r < kSortItems; ++r) {
         const int64_t i = wbase + r * 64 + lane;
         const bool valid = i < D;
-        key[r] = valid ? keys_in[i] : ~0ull;
+        key[r] = valid ? keys_in[i] : ~0u;
         val[r] = valid ? vals_in[i] : 0u;
         const uint32_t d = digit_of(key[r], shift);
         uint64_t peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < kRadixBits; ++b) {
-            const uint64_t m = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? m : ~m;
+            if (b < nbits) {
+                const uint64_t m = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? m : ~m;
+            }
         }
         // all lanes in `peers` share digit d (invalid lanes excluded)
         const uint32_t before = wcount[w][d];  // read before the leader updates it
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(
     for (int r = 0; r < kSortItems; ++r) {
         const uint32_t p = r * kSortThreads + threadIdx.x;
         if (p < n_valid) {
-            const uint64_t k = lkey[p];
+            const uint32_t k = lkey[p];
             const uint32_t dst = gbase[digit_of(k, shift)] + p;
             keys_out[dst] = k;
             vals_out[dst] = lval[p];
@@ -272,17 +276,17 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(
     }
 }
 
-// Per-tile ranges from the tile-ordered keys.
-__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint64_t* __restrict__ keys,
+// Per-tile ranges from the tile-ordered tile numbers.
+__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ tkeys,
                                                           int64_t D, uint32_t* __restrict__ ranges,
                                                           const uint32_t* __restrict__ tail, int T) {
     if (tail) D = min(D, (int64_t)tail[2]);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= D) return;
-    const uint32_t t = (uint32_t)(keys[i] >> 32);
+    const uint32_t t = tkeys[i];
     if (t >= (uint32_t)T) return;
-    if (i == 0 || (uint32_t)(keys[i - 1] >> 32) != t) ranges[2 * t] = (uint32_t)i;
-    if (i == D - 1 || (uint32_t)(keys[i + 1] >> 32) != t) ranges[2 * t + 1] = (uint32_t)(i + 1);
+    if (i == 0 || tkeys[i - 1] != t) ranges[2 * t] = (uint32_t)i;
+    if (i == D - 1 || tkeys[i + 1] != t) ranges[2 * t + 1] = (uint32_t)(i + 1);
 }
 
 // Ascending bitonic network over the first P (a power of two >= 64) entries of s, 256 lanes.
@@ -411,21 +415,27 @@ __device__ __forceinline__ void lds_sort(SortShared& sh, uint32_t n) {
     __syncthreads();
 }
 
-// One workgroup per tile: orders the tile's list by (depth bits, splat index), in place.  The
-// list arrives in splat order (the radix passes are stable), keys = tile << 32 | depth bits.
+// One workgroup per tile: gathers the depths of the tile's list (`ids`, in splat order: the radix
+// passes are stable), orders it by (depth bits, splat index) and writes keys = tile << 32 |
+// depth bits and vals = splat index into the caller's arrays.
 __global__ __launch_bounds__(256) void tile_depth_sort_kernel(
-    const uint32_t* __restrict__ ranges, uint64_t* keys, uint32_t* vals, uint64_t* scratch) {
+    const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ ids,
+    const float* __restrict__ depth, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+    uint64_t* __restrict__ scratch) {
     __shared__ SortShared sh;
     const uint32_t t = blockIdx.x;
     const uint2 rg = reinterpret_cast<const uint2*>(ranges)[t];
     const uint32_t b = rg.x, n = rg.y - rg.x;
-    if (n < 2u) return;                      // a list of one entry is in order as it is
+    if (n == 0u) return;
     const uint64_t tile_hi = (uint64_t)t << 32;
+    auto composite = [&](uint32_t i) {
+        const uint32_t id = ids[b + i];
+        return ((uint64_t)__float_as_uint(depth[id]) << 32) | (uint64_t)id;
+    };
     if (n <= (uint32_t)kSortCap) {
-        for (uint32_t i = threadIdx.x; i < n; i += 256)
-            sh.s[i] = (keys[b + i] << 32) | (uint64_t)vals[b + i];
+        for (uint32_t i = threadIdx.x; i < n; i += 256) sh.s[i] = composite(i);
         __syncthreads();
-        lds_sort(sh, n);
+        if (n > 1u) lds_sort(sh, n);
         for (uint32_t i = threadIdx.x; i < n; i += 256) {
             const uint64_t c = sh.s[i];
             keys[b + i] = tile_hi | (c >> 32);
@@ -435,14 +445,13 @@ __global__ __launch_bounds__(256) void tile_depth_sort_kernel(
     }
     // A list the LDS does not hold: runs of kSortCap composites sorted in LDS and parked in the
     // scratch buffer, then merged pairwise, alternating between the scratch buffer and the
-    // tile's own stretch of the key array (all of its keys have been read by then); every pair
-    // of runs is cut into 256 equal output pieces along its merge path.
+    // tile's own stretch of the key array (nothing else lives there); every pair of runs is cut
+    // into 256 equal output pieces along its merge path.
     uint64_t* A = scratch + b;
     uint64_t* B = keys + b;
     for (uint32_t r0 = 0; r0 < n; r0 += kSortCap) {
         const uint32_t len = min((uint32_t)kSortCap, n - r0);
-        for (uint32_t i = threadIdx.x; i < len; i += 256)
-            sh.s[i] = (B[r0 + i] << 32) | (uint64_t)vals[b + r0 + i];
+        for (uint32_t i = threadIdx.x; i < len; i += 256) sh.s[i] = composite(r0 + i);
         __syncthreads();
         lds_sort(sh, len);
         for (uint32_t i = threadIdx.x; i < len; i += 256) A[r0 + i] = sh.s[i];
@@ -531,10 +540,11 @@ static int bits_for(uint32_t span) {   // bits needed to hold values 0..span
 }
 
 struct BinWorkspace {
-    uint64_t* keys_alt;
-    uint32_t* vals_alt;
-    uint32_t* ghist;  // [256] digit totals of the current pass
-    uint32_t* thist;  // [256][ntiles]
+    uint32_t* pairs;   // [2][D]: tile numbers, then splat indices (one side of the ping-pong; the
+                       // other side borrows the caller's key array until the last stage fills it)
+    uint64_t* merge;   // [D]: merge space of the depth sort for lists the LDS does not hold
+    uint32_t* ghist;   // [256] digit totals of the current pass
+    uint32_t* thist;   // [256][ntiles]
     size_t bytes;
 };
 
@@ -545,8 +555,8 @@ static BinWorkspace carve(void* ws, int64_t D) {
     const int ntiles = cdiv(D > 0 ? D : 1, kSortTile);
     size_t off = 0;
     char* p = (char*)ws;
-    b.keys_alt = (uint64_t*)(p + off); off += align256(sizeof(uint64_t) * (size_t)(D > 0 ? D : 1));
-    b.vals_alt = (uint32_t*)(p + off); off += align256(sizeof(uint32_t) * (size_t)(D > 0 ? D : 1));
+    b.pairs = (uint32_t*)(p + off); off += align256(2 * sizeof(uint32_t) * (size_t)(D > 0 ? D : 1));
+    b.merge = (uint64_t*)(p + off); off += align256(sizeof(uint64_t) * (size_t)(D > 0 ? D : 1));
     b.ghist = (uint32_t*)(p + off);    off += align256(sizeof(uint32_t) * kMaxPasses * kRadix);
     b.thist = (uint32_t*)(p + off);    off += align256(sizeof(uint32_t) * kRadix * (size_t)ntiles);
     b.bytes = off;
@@ -590,17 +600,20 @@ static int bin_impl(int N, int H, int W, int64_t D, const uint32_t* tail, const 
     const int passes = tile_bits > 0 ? (tile_bits + kRadixBits - 1) / kRadixBits : 1;
     VINGS_REQUIRE(passes <= kMaxPasses, "too many tiles");
     ProfScope prof(PROF_BIN, s);
-    // ping-pong so that the last pass leaves keys and values in the caller's arrays
-    uint64_t* kbuf[2] = {keys_sorted, b.keys_alt};
-    uint32_t* vbuf[2] = {vals_sorted, b.vals_alt};
-    int cur = passes & 1;
+    // (tile, splat) pairs as two 32-bit arrays of D entries each.  Ping-pong between the
+    // caller's key array (its 8 D bytes hold one such pair of arrays) and the workspace, so that
+    // the last pass leaves the pairs in the WORKSPACE: the depth sort then fills the caller's
+    // keys and values from there.
+    uint32_t* kbuf[2] = {reinterpret_cast<uint32_t*>(keys_sorted), b.pairs};
+    uint32_t* vbuf[2] = {reinterpret_cast<uint32_t*>(keys_sorted) + D, b.pairs + D};
+    int cur = (passes & 1) ? 0 : 1;
 
-    emit_keys_kernel<<<cdiv(N, 256), 256, 0, s>>>(N, gx, depth, rect, tiles_touched, block_prefix,
+    emit_keys_kernel<<<cdiv(N, 256), 256, 0, s>>>(N, gx, rect, tiles_touched, block_prefix,
                                                   kbuf[cur], vbuf[cur], ranges, 2 * T, (uint32_t)D);
     VINGS_LAUNCH_CHECK();
     const int ntiles = cdiv(D, kSortTile);
     for (int p = 0; p < passes; ++p) {
-        const int shift = 32 + p * kRadixBits;
+        const int shift = p * kRadixBits;
         sort_tile_hist_kernel<<<ntiles, kSortThreads, 0, s>>>(kbuf[cur], D, shift, ntiles, b.thist,
                                                               tail);
         VINGS_LAUNCH_CHECK();
@@ -608,14 +621,16 @@ static int bin_impl(int N, int H, int W, int64_t D, const uint32_t* tail, const 
         VINGS_LAUNCH_CHECK();
         sort_scatter_kernel<<<ntiles, kSortThreads, 0, s>>>(kbuf[cur], vbuf[cur], kbuf[cur ^ 1],
                                                             vbuf[cur ^ 1], D, shift, ntiles,
-                                                            b.thist, b.ghist, tail);
+                                                            b.thist, b.ghist, tail,
+                                                            min(kRadixBits, max(1, tile_bits - shift)));
         VINGS_LAUNCH_CHECK();
         cur ^= 1;
     }
-    // cur == 0 here: the tile-ordered lists are in keys_sorted / vals_sorted
-    tile_ranges_kernel<<<cdiv(D, 256), 256, 0, s>>>(keys_sorted, D, ranges, tail, T);
+    // cur == 1 here: the tile-ordered pairs are in the workspace
+    tile_ranges_kernel<<<cdiv(D, 256), 256, 0, s>>>(kbuf[1], D, ranges, tail, T);
     VINGS_LAUNCH_CHECK();
-    tile_depth_sort_kernel<<<T, 256, 0, s>>>(ranges, keys_sorted, vals_sorted, b.keys_alt);
+    tile_depth_sort_kernel<<<T, 256, 0, s>>>(ranges, vbuf[1], depth, keys_sorted, vals_sorted,
+                                             b.merge);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }
