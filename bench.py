@@ -351,7 +351,9 @@ def main():
                         "launch stream); traffic is NOT: it is the FETCH_SIZE / WRITE_SIZE "
                         "figure of the committed rocprofv3 PMC passes of this same workload "
                         "(profiles/, null for any other workload).  The kernel is bound by "
-                        "vector-instruction issue, not by HBM (profiles/*/blend_sq_counters.txt); "
+                        "vector-instruction issue, not by HBM (profiles/*/blend_sq_counters.txt: "
+                        "7.46e8 VALU wave-instructions per launch on 1024 SIMDs, 3.3 cycles each "
+                        "at 2.4 GHz = the measured millisecond); "
                         "more than half of the traffic is its write side, one 80-byte float atomic "
                         "per (8x8 pixel block, splat) pair where the algorithmic count has one "
                         "84-byte row per visible splat (an LDS accumulator per tile halves it and "
