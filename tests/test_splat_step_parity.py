@@ -409,3 +409,29 @@ def test_fused_view_with_nothing_in_view_changes_nothing():
     torch.cuda.synchronize()
     assert m.last_stats()["D"] > 0
     assert not torch.equal(m.params["_xyz"].detach(), before["_xyz"])
+
+
+@pytest.mark.parametrize("W,H,n", [(20, 12, 60), (16, 16, 1), (47, 33, 400)])
+def test_fused_view_on_tiny_images(W, H, n):
+    """One tile, a partial tile, a handful of splats: the fused step (ordered blend passes, tile
+    order of 1..6 tiles, batches of far fewer than 256 records) against the autograd-driven
+    step on the same inputs."""
+    dev = torch.device(DEV)
+    raw = synth.make_splats(n, W, H, n_views=1, seed=29, z_range=(2.0, 6.0))
+    intr = synth.intrinsic_for(W, H)
+    w2c = torch.linalg.inv(synth.window_poses(1)[0]).to(dev)
+    gtp = {k: v.to(dev) for k, v in synth.perturb_splats(raw).items()}
+    with torch.no_grad():
+        pr = harness.render(gtp, w2c, intr)
+    gt = {"rgb": pr["rgb"].clone(), "depth": pr["depth"].clone(), "depth_cov": torch.ones_like(pr["depth"])}
+    a, b = harness.SurfelMapper(raw, dev), harness.SurfelMapper(raw, dev)
+    radii, cur = a.backward_view(w2c, intr, gt)
+    a.finish_view(radii, cur, 0)
+    b.fused_view(harness.view_settings(w2c, intr), intr, gt, w2c[:3, :3].cpu(), 0)
+    torch.cuda.synchronize()
+    assert abs(float(a.last_loss) - float(b.last_loss)) <= 1e-4 * abs(float(a.last_loss)) + 1e-7
+    for k in a.NAMES:
+        x = a.optimizer.state[a.params[k]]["exp_avg"]
+        y = b.optimizer.state[b.params[k]]["exp_avg"]
+        assert torch.isfinite(y).all()
+        assert float((x - y).abs().max()) <= 2e-3 * float(x.abs().max()) + 1e-12, k
