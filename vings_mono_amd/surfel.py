@@ -357,6 +357,14 @@ def blend_backward(st, aux, g_color, g_allmap, dgeom=None, lean=False):
                   ptr(st.final_T), ptr(st.n_contrib), ptr(g_color), ptr(g_allmap), ptr(dgeom),
                   stream_ptr(dev)), "vings_surfel_blend_backward_accumulate")
         return dgeom
+    if st.tile_order is not None:
+        # (the full pass in the forward pass's tile order; the ordered entry adds into its rows)
+        dgeom = torch.zeros((max(N, 1), GRAD_STRIDE), dtype=torch.float32, device=dev)
+        check(L.vings_surfel_blend_backward_accumulate_ordered(
+            0, N, H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg), ptr(mask),
+            ptr(st.final_T), ptr(st.n_contrib), ptr(g_color), ptr(g_allmap), ptr(dgeom),
+            ptr(st.tile_order), stream_ptr(dev)), "vings_surfel_blend_backward_accumulate_ordered")
+        return dgeom
     dgeom = torch.empty((max(N, 1), GRAD_STRIDE), dtype=torch.float32, device=dev)
     check(L.vings_surfel_blend_backward(
         N, H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg), ptr(mask), ptr(st.final_T),
@@ -401,7 +409,8 @@ class _RasterizeSurfels(torch.autograd.Function):
                 or opacities.numel() != N:
             raise _lib.VingsError(
                 "expected means3D[N,3] colors[N,3] opacities[N,1] scales[N,2] rotations[N,4]")
-        st, aux = rasterize_forward(means3D, colors, opacities, scales, rotations, settings)
+        st, aux = rasterize_forward(means3D, colors, opacities, scales, rotations, settings,
+                                    order_tiles=True)
         ctx.st, ctx.aux = st, aux
         ctx.scale_modifier = float(settings.scale_modifier)
         ctx.has_means2D = means2D is not None
