@@ -10,16 +10,17 @@ Adam, plus one dense bundle-adjustment call ``ba(itrs=2)`` per window.
 
     python bench.py --gpus N --steps K --warmup W
 
-For N>1 the driver launches this file under torch.distributed.run, one rank
-per GPU.  Rank 0 prints ONE JSON line.
+For N>1 there is one rank per GPU.  Started under torch.distributed.run (WORLD_SIZE
+set) this process is one of the ranks; started plainly with --gpus N > 1 it
+starts the N ranks itself as children (before anything here touches a GPU) and
+hands on rank 0's line and the children's exit code.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -32,16 +33,24 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--workload", choices=("auto", "c3", "c4", "c5"), default="auto",
-                    help="BASELINE config: c3 = 8-keyframe window + DBA on every GPU (the one the "
-                         "metric is quoted on); c4 = one 32-keyframe window whose keyframes are "
-                         "dealt out over the GPUs (4 per GPU at 8); c5 = 5.0M splats, 8 keyframes "
-                         "dealt out over the GPUs + DBA + the GPU side of one loop closure over 64 "
-                         "history keyframes per step; auto = c4 at 8 GPUs, else c3")
-    ap.add_argument("--splats", type=int, default=None, help="default 1.0M (c5: 5.0M)")
+    ap.add_argument("--workload", choices=("c3", "c4", "c5", "native"), default="c3",
+                    help="BASELINE config: c3 (default at every N: the same scene and the same work "
+                         "per GPU, so the 1/2/4/8 figures form one weak-scaling curve) = 8-keyframe "
+                         "window + DBA on every GPU, the one the metric is quoted on; c4 = one "
+                         "32-keyframe window whose keyframes are dealt out over the GPUs (4 per GPU "
+                         "at 8); c5 = 5.0M splats, 8 keyframes dealt out over the GPUs + DBA + the "
+                         "GPU side of one loop closure over 64 history keyframes per step, its "
+                         "keyframes dealt out over the GPUs too; native = the reference's own "
+                         "operating point (344x616, 300k splats, 43x77 DBA grid)")
+    ap.add_argument("--scene", choices=("frustum", "surfaces"), default="frustum",
+                    help="frustum: splats spread through the window's frustum union (the metric's "
+                         "scene); surfaces: opaque walls and a ground plane with a 10x spread of "
+                         "list lengths (a side workload)")
+    ap.add_argument("--splats", type=int, default=None,
+                    help="default 1.0M (c5: 5.0M, native: 0.3M)")
     ap.add_argument("--loop-keyframes", type=int, default=64, help="c5: history keyframes K")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=None, help="default 1920 (native: 616)")
+    ap.add_argument("--height", type=int, default=None, help="default 1080 (native: 344)")
     ap.add_argument("--views", type=int, default=None,
                     help="keyframes per GPU per step (default: 8 for c3, 32 / GPUs for c4)")
     ap.add_argument("--binning", choices=("tight", "reference"), default="tight",
@@ -77,7 +86,7 @@ def parse():
                          "instead of the fused C-ABI sequence")
     ap.add_argument("--torch-loss", action="store_true",
                     help="build the PyTorch loss graph instead of the fused HIP loss kernels")
-    ap.add_argument("--dba-grid", type=str, default="135x240")
+    ap.add_argument("--dba-grid", type=str, default=None, help="default 135x240 (native: 43x77)")
     return ap.parse_args()
 
 
@@ -105,8 +114,36 @@ def measured_traffic(splats, W, H):
     return None
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as
+    children of a process that never touches a GPU (one rank per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1), pass rank 0's JSON line on and exit with
+    the children's code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    if proc.returncode == 0 and not lines:
+        print("bench.py: the ranks exited cleanly without a result line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.rehearse_rccl:
+        raise SystemExit(self_launch(args))
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -117,7 +154,7 @@ def main():
     if args.rehearse_gloo:
         local_rank = 0
         import faulthandler
-        faulthandler.dump_traceback_later(90, exit=True)       # a stuck rehearsal names its line
+        faulthandler.dump_traceback_later(150, exit=True)      # a stuck rehearsal names its line
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     json_out = sys.stdout
@@ -127,6 +164,7 @@ def main():
         sys.stdout.flush()
         json_out = os.fdopen(os.dup(1), "w")
         os.dup2(2, 1)
+    ranks_seen, comm = 1, None
     if args.rehearse_rccl:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -139,16 +177,34 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus or world == 1 and args.gpus == 1, \
-        f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1 or args.rehearse_rccl:
+        # every rank adds a one: the line says how many ranks really took part
+        ones = torch.ones(1, dtype=torch.int64, device="cpu" if args.rehearse_gloo else dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        comm = {"backend": dist.get_backend(), "ranks_seen": ranks_seen}
+        if dist.get_backend() == "nccl":
+            comm["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
 
     from vings_mono_amd import harness, synth, parallel, profiling, surfel
     workload = args.workload
-    if workload == "auto":
-        workload = "c4" if world == 8 else "c3"
-    W, H = args.width, args.height
+    native = workload == "native"
+    if native:
+        # The reference's own operating point: the mapper works at the tracker's image size
+        # (frontend.image_size 344x616, /root/reference/configs/hierarchical/smallcity.yaml:42)
+        # on a map that grows by <= 40k splats per keyframe, and the tracker's BA runs on the
+        # 43x77 grid.  Same step as c3 otherwise.
+        workload = "c3"
+    W = args.width or (616 if native else 1920)
+    H = args.height or (344 if native else 1080)
+    args.width, args.height = W, H
     if args.splats is None:
-        args.splats = 5_000_000 if workload == "c5" else 1_000_000
+        args.splats = 5_000_000 if workload == "c5" else 300_000 if native else 1_000_000
+    if args.dba_grid is None:
+        args.dba_grid = "43x77" if native else "135x240"
+    make_scene = synth.make_surface_splats if args.scene == "surfaces" else synth.make_splats
     intr = synth.intrinsic_for(W, H)
     surfel.set_tight_binning(args.binning == "tight")
     loop = None
@@ -156,10 +212,11 @@ def main():
         # BASELINE config 5: a 5.0M-splat map along a street of K history keyframes; the 8 most
         # recent keyframes are the mapping window, dealt out over the GPUs (1 per GPU at 8).
         # Every step also runs the GPU side of one loop closure over all K keyframes
-        # (loop_model.py:169-214, loop_rectify.py:300-437).  That part is not sharded: every
-        # rank does it on its own replica ("replicas only"), with an identity correction so
-        # that the map of the next step is the same.  The pose-graph solve itself (scipy /
-        # GTSAM on the host) is not part of this path.
+        # (loop_model.py:169-214, loop_rectify.py:300-437): the K scoring passes and the K depth
+        # renders are dealt out over the ranks (records merged / maps gathered), the per-splat
+        # re-anchor runs on every replica, with an identity correction so that the map of the
+        # next step is the same.  The pose-graph solve itself (scipy / GTSAM on the host) is
+        # not part of this path.
         K = args.loop_keyframes
         window = 8
         V = args.views or max(1, window // world)
@@ -175,7 +232,7 @@ def main():
         # scaling) instead of thinning out as the window would stretch over more keyframes.
         V = args.views or 8
         window = V
-        raw = synth.make_splats(args.splats, W, H, n_views=V, seed=synth.SEED_BASE)
+        raw = make_scene(args.splats, W, H, n_views=V, seed=synth.SEED_BASE)
         c2w_rank = synth.window_poses(V)
         c2w_rank[:, 1, 3] += 0.05 * rank
     else:
@@ -184,7 +241,7 @@ def main():
         # frustum union of all 32.
         window = 32
         V = args.views or max(1, window // world)
-        raw = synth.make_splats(args.splats, W, H, n_views=window, seed=synth.SEED_BASE)
+        raw = make_scene(args.splats, W, H, n_views=window, seed=synth.SEED_BASE)
         c2w_rank = synth.window_poses(window)[(rank * V) % window:][:V]
         assert c2w_rank.shape[0] == V, "views per GPU x GPUs must fit the 32-keyframe window"
     n_views_total = V * world
@@ -218,12 +275,12 @@ def main():
         K = loop["K"]
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
-        scores3, ids3 = maintenance.calc_score(mapper, loop["c2w"], list(range(K)), intr)
+        scores3, ids3 = maintenance.calc_score(mapper, loop["c2w"], list(range(K)), intr, reducer)
         ev[1].record()
         maintenance.rectify_gaussians(mapper, loop["stack"], loop["stack"], torch.ones(K), 0, K - 1,
                                       scores3, ids3, delete_below=-1.0)
         ev[2].record()
-        maintenance.rectify_tracker(mapper, loop["c2w"], intr, loop["dense"], loop["coarse"])
+        maintenance.rectify_tracker(mapper, loop["c2w"], intr, loop["dense"], loop["coarse"], reducer)
         ev[3].record()
         loop["events"] = ev
 
@@ -242,7 +299,7 @@ def main():
     dba_side = torch.cuda.Stream(device=dev) if (dba is not None and args.dba_stream == "side") else None
     dba_done = torch.cuda.Event() if dba_side is not None else None
 
-    def step(autograd=args.autograd, torch_loss=args.torch_loss, graphed=False):
+    def step(autograd=args.autograd, torch_loss=args.torch_loss, graphed=False, full_passes=False):
         if dba_side is not None:
             # the window's BA beside its view steps; it starts behind everything already queued
             dba_side.wait_stream(torch.cuda.current_stream(dev))
@@ -259,7 +316,8 @@ def main():
                                                   torch_loss=torch_loss)
                 mapper.finish_view(radii, cur, k, reducer)
             else:
-                mapper.fused_view(cams[i], intr, gts[i], R_host[i], k, reducer)
+                mapper.fused_view(cams[i], intr, gts[i], R_host[i], k, reducer,
+                                  lean=False if full_passes else None)
         # the record maxima of the window (best keyframe, error score) are merged over the ranks
         # here, once per window, behind the bundle adjustment
         finish_records = mapper.sync_records(reducer, async_op=True)
@@ -317,7 +375,7 @@ def main():
         barrier()
         return round(n_views_total * n_steps / (time.perf_counter() - t), 3)
 
-    reference_api = reference_binning = graph_replay = autograd_api = None
+    reference_api = reference_binning = graph_replay = autograd_api = full_passes = None
     if args.rehearse_rccl:
         args.no_side_runs = True
     if world == 1 and not args.no_side_runs and not args.no_graph_run and loop is None \
@@ -333,6 +391,7 @@ def main():
         # the same loop with one call changed: the loss through harness.mapping_loss_fused (the
         # fused HIP kernels behind a differentiable scalar) instead of the PyTorch loss graph
         autograd_api = side_run(autograd=True, torch_loss=False)
+        full_passes = side_run(full_passes=True)
         if args.binning == "tight":
             surfel.set_tight_binning(False)
             reference_binning = side_run()
@@ -382,21 +441,26 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "mapping frames/sec (render+bwd+BA) @1M splats 1920x1080",
-            "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "metric": "mapping frames/sec (render+bwd%s) @%gM splats %dx%d" % (
+                "" if dba is None else "+BA", args.splats / 1e6, W, H),
+            "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "ranks_seen": ranks_seen,
+            "comm": comm, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" + (" (gloo rehearsal on one GPU: not a benchmark result)" if args.rehearse_gloo else "")
                     + (" (one-rank RCCL rehearsal of the multi-GPU step: not a benchmark result)" if args.rehearse_rccl else ""),
-            "config": {"workload": ("BASELINE config %s: %.1fM splats, %s %dx%d%s" % (
-                                        workload[1], args.splats / 1e6,
+            "config": {"workload": ("%s: %.1fM splats, %s %dx%d%s" % (
+                                        "the reference's own operating point (smallcity.yaml), stepped like BASELINE config 3"
+                                        if native else "BASELINE config " + workload[1], args.splats / 1e6,
                                         ("%d-keyframe window per GPU" % V) if workload == "c3" else
                                         ("one %d-keyframe window, %d keyframes per GPU" % (window, V)),
                                         W, H, ("" if dba is None else " + DBA step per GPU") +
                                         ("" if loop is None else " + loop closure over %d keyframes "
-                                         "per step (scoring, re-anchor, tracker refresh; replicated "
-                                         "on every GPU; pose-graph solve excluded)" % loop["K"]))),
-                       "binning": args.binning,
+                                         "per step (scoring and tracker refresh dealt out over the GPUs, "
+                                         "re-anchor on every replica; pose-graph solve excluded)" % loop["K"]))),
+                       "scene": args.scene, "binning": args.binning,
+                       "blend": "lean (no median-depth / flow planes: the mapping loss has no term "
+                                "in them; full_passes = the drop-in rasteriser's passes)",
                        "view_step": "autograd" if (args.autograd or args.torch_loss) else "fused C-ABI sequence",
                        "loss": "torch graph" if args.torch_loss else "fused HIP kernels",
                        "splats": args.splats, "width": W, "height": H, "views_per_gpu": V,
@@ -417,6 +481,10 @@ def main():
                 "what": "the reference's call pattern with the loss taken from "
                         "harness.mapping_loss_fused: GaussianRasterizer through autograd, "
                         "loss.backward(), PyTorch score bookkeeping, SparseGaussianAdam.step"},
+            "full_passes": None if full_passes is None else {
+                "value": full_passes, "unit": "frames/s",
+                "what": "the fused step with the full blend passes (median depth and flow planes "
+                        "computed) instead of the lean ones"},
             "graph_replay": None if graph_replay is None else {
                 "value": graph_replay, "unit": "frames/s",
                 "what": "the same fused step with every view replayed from a HIP graph captured "

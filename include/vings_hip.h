@@ -508,6 +508,16 @@ int vings_splat_top3_update(int N, const float* cur_importance, int kf_id, float
 int vings_splat_top3_update_gated(int N, const float* cur_importance, int kf_id, float* scores3,
                                   int32_t* kfids3, const float* gate, float gate_min,
                                   void* stream);
+/* Multi-GPU form of the scoring: the keyframe sequence of loop/loop_model.py:174 is dealt out
+ * over R ranks in contiguous blocks (rank 0 the earliest keyframes), every rank builds its
+ * record over its block with vings_splat_top3_update*, the records are gathered
+ * (scores_all, kfids_all: [R,N,3], rank-major) and merged here.  The entries of rank r's
+ * record pass through the same strict comparisons (loop_model.py:190-211), best first, ranks
+ * in order: equal scores keep the earlier keyframe and empty slots (score 0) never enter, so
+ * scores3 / kfids3 [N,3] equal what one pass over all keyframes leaves, bit for bit.  The
+ * outputs must not alias the inputs. */
+int vings_splat_top3_merge(int N, int R, const float* scores_all, const int32_t* kfids_all,
+                           float* scores3, int32_t* kfids3, void* stream);
 int vings_splat_reanchor(int N, float* xyz, float* rotation, const int32_t* owner_kf,
                          int owner_stride, int kf_start, int kf_end, int K, const float* old_w2c,
                          const float* new_c2w, const float* delta_quat, const float* scale,

@@ -63,8 +63,27 @@ def main():
     for m, r in ((a, red), (b, red), (c, red_c), (d, red_d)):  # ... and the overlapped form at the end
         fin = m.sync_records(r, async_op=True)
         fin()
+    # GPU side of a loop closure over 7 keyframes (not a multiple of 2 or 4: the last rank's
+    # block is short or empty): scoring and tracker refresh dealt out over the ranks against the
+    # same calls on this rank alone
+    Kl = 7
+    kf_c2w = [synth.window_poses(Kl)[i].to(dev) for i in range(Kl)]
+    s_one, i_one = maintenance.calc_score(b, kf_c2w, list(range(20, 20 + Kl)), intr)
+    s_all, i_all = maintenance.calc_score(b, kf_c2w, list(range(20, 20 + Kl)), intr, red)
+    maps = []
+    for r_ in (None, red):
+        dense = torch.full((Kl, H, W), 0.5, device=dev)
+        coarse = torch.zeros((Kl, H // 8, W // 8), device=dev)
+        maintenance.rectify_tracker(b, kf_c2w, intr, dense, coarse, r_)
+        maps.append((dense, coarse))
     torch.cuda.synchronize()
-    state = {"rank": rank, "exchanged_rows": exchanged}
+    state = {"rank": rank, "exchanged_rows": exchanged,
+             "loop": {"scores_err": float(((s_one - s_all).abs() / (s_one.abs() + 1e-3)).max()),
+                      "ids_match": float((i_one == i_all).float().mean()),
+                      "dense_equal": bool(torch.equal(maps[0][0], maps[1][0])),
+                      "coarse_equal": bool(torch.equal(maps[0][1], maps[1][1])),
+                      "scored": int((s_all[:, 0] > 0).sum()), "kf_seen": int(len(torch.unique(i_all[:, 0]))),
+                      "refreshed": int((maps[1][0] != 0.5).sum())}}
     for name, m in (("autograd", a), ("fused", b), ("fused_synced_first", c), ("fused_planar", d)):
         state[name] = {k: m.params[k].detach().cpu() for k in m.NAMES}
         state[name]["global_scores"] = m.global_scores.cpu()

@@ -294,3 +294,21 @@ def test_profile_select_limits_the_timed_stages():
     profiling.select(None)
     profiling.enable(False)
     assert set(got) == {"blend_fwd"} and got["blend_fwd"]["count"] == 1
+
+
+def test_bench_self_launch_plumbing():
+    """`bench.py --gpus 2` started plainly becomes a launcher that never touches a GPU: it starts
+    two ranks under torch.distributed.run and hands on their exit code.  There is no GPU here,
+    so both ranks stop at the library's "no CPU path" message: that message, twice, shows that
+    they were started as ranks of a 2-rank job; the parent's code is non-zero because theirs is."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
+                          "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0
+    assert res.stderr.count("bench.py needs a GPU") >= 2, res.stderr[-3000:]
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]

@@ -137,6 +137,38 @@ def test_top3_update_matches_reference_logic():
     np.testing.assert_array_equal(tk.cpu().numpy(), k)
 
 
+@pytest.mark.parametrize("ranks", [2, 3, 8])
+def test_top3_merge_of_rank_records_equals_the_sequential_pass(ranks):
+    """The keyframes dealt out over `ranks` in contiguous blocks, one record per block, merged:
+    bit for bit the record of the sequential pass (loop_model.py:190-211), ties (scores on a
+    coarse grid: most splats see equal scores from several keyframes) and empty slots included."""
+    from oracle import mapper_oracle as mo
+    from vings_mono_amd import _lib
+    L = _lib.lib()
+    n, K = 4000, 13
+    rng = np.random.default_rng(5 + ranks)
+    curs = [(np.round(rng.random(n) * 6) / 6 * (rng.random(n) > 0.4)).astype(np.float32) for _ in range(K)]
+    s, k = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.int32)
+    for kf in range(K):
+        s, k = mo.top3_update(s, k, curs[kf], kf + 3)
+    per = -(-K // ranks)
+    stream = _lib.stream_ptr(torch.device(DEV))
+    all_s = torch.zeros((ranks, n, 3), dtype=torch.float32, device=DEV)
+    all_k = torch.zeros((ranks, n, 3), dtype=torch.int32, device=DEV)
+    for r in range(ranks):
+        for kf in range(r * per, min(K, (r + 1) * per)):
+            tc = torch.from_numpy(curs[kf]).to(DEV)
+            _lib.check(L.vings_splat_top3_update(n, _lib.ptr(tc), kf + 3, _lib.ptr(all_s[r]),
+                                                 _lib.ptr(all_k[r]), stream), "top3")
+    out_s = torch.empty((n, 3), dtype=torch.float32, device=DEV)
+    out_k = torch.empty((n, 3), dtype=torch.int32, device=DEV)
+    _lib.check(L.vings_splat_top3_merge(n, ranks, _lib.ptr(all_s), _lib.ptr(all_k), _lib.ptr(out_s),
+                                        _lib.ptr(out_k), stream), "top3 merge")
+    np.testing.assert_array_equal(out_s.cpu().numpy(), s)
+    np.testing.assert_array_equal(out_k.cpu().numpy(), k)
+    assert (s[:, 0] == s[:, 1]).sum() == (s[:, 0] == 0).sum()       # ties never entered twice
+
+
 def test_calc_score_and_rectify_gaussians():
     from oracle import mapper_oracle as mo
     dev = torch.device(DEV)

@@ -38,6 +38,15 @@ def test_multi_rank_view_steps(tmp_path, world):
             for k in names + ("global_scores", "local_scores", "kf_id", "kf_max"):
                 assert torch.equal(s0[impl][k], s1[impl][k]), f"{impl}: replicas 0 and {r} differ in {k}"
         assert s1["exchanged_rows"] == s0["exchanged_rows"]
+    # loop closure dealt out over the ranks = the same calls on one rank: the depth maps bit for
+    # bit; the scores to what two runs of the importance pass differ by (its per-tile partial
+    # sums meet in float atomics; the merge itself is checked bit-exact in
+    # test_maintenance_parity.py), near-ties between keyframes may then swap owners
+    for r in range(world):
+        lp = torch.load(out + f".rank{r}.pt", weights_only=True)["loop"]
+        assert lp["dense_equal"] and lp["coarse_equal"], (r, lp)
+        assert lp["scores_err"] <= 1e-4 and lp["ids_match"] >= 0.999, (r, lp)
+        assert lp["scored"] > 1000 and lp["kf_seen"] > 2 and lp["refreshed"] > 1000, lp
     # the compact exchange moved the rows some rank saw, not the whole map
     assert all(0 < m < 5300 for m in s0["exchanged_rows"]), s0["exchanged_rows"]
     # compact against planar exchange of the same fused step (two runs of the blend backward:
@@ -76,6 +85,27 @@ def test_multi_rank_view_steps(tmp_path, world):
     for k in ("global_scores", "local_scores", "kf_max"):
         scale = float(s0["autograd"][k].abs().max())
         assert float((s0["autograd"][k] - s0["fused"][k]).abs().max()) <= 1e-4 * scale, k
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the way the driver starts the
+    bench): the process starts its two ranks itself and hands on rank 0's line."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK")}
+    env["OMP_NUM_THREADS"] = "2"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-gloo",
+           "--splats", "200000", "--width", "960", "--height", "544", "--steps", "1", "--warmup", "1"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["comm"]["backend"] == "gloo"
+    assert rec["metric"] == "mapping frames/sec (render+bwd+BA) @0.2M splats 960x544"
+    assert "config 3" in rec["config"]["workload"] and rec["value"] > 0
+    assert rec["config"]["exchange"]["form"] == "compact"
 
 
 def test_exchange_over_rccl_one_rank(tmp_path):

@@ -69,6 +69,7 @@ _SIGNATURES = {
     "vings_depth_refresh": (_c.c_int, [_c.c_int, _c.c_int] + [_P] * 5),
     "vings_splat_top3_update": (_c.c_int, [_c.c_int, _P, _c.c_int, _P, _P, _P]),
     "vings_splat_top3_update_gated": (_c.c_int, [_c.c_int, _P, _c.c_int, _P, _P, _P, _c.c_float, _P]),
+    "vings_splat_top3_merge": (_c.c_int, [_c.c_int, _c.c_int] + [_P] * 5),
     "vings_splat_reanchor": (_c.c_int, [_c.c_int, _P, _P, _P] + [_c.c_int] * 4 + [_P] * 5),
     "vings_splat_pack_exchange": (_c.c_int, [_c.c_int] + [_P] * 7 + [_c.c_int64] + [_P] * 3),
     "vings_splat_unpack_exchange": (_c.c_int, [_c.c_int] + [_P] * 10),

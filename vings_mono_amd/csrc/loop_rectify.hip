@@ -34,6 +34,36 @@ __global__ __launch_bounds__(256) void splat_top3_update_kernel(int N, const flo
     }
 }
 
+// Records of R ranks, each built over its own contiguous block of the keyframe sequence
+// (rank 0 the earliest): the entries of rank r's record pass through the same strict update,
+// best first, ranks in order.  Equal scores therefore keep the earlier keyframe and an empty
+// slot (score 0) never enters, which is what the sequential pass over all keyframes leaves.
+__global__ __launch_bounds__(256) void splat_top3_merge_kernel(int N, int R,
+                                                               const float* __restrict__ scores_all,
+                                                               const int32_t* __restrict__ ids_all,
+                                                               float* __restrict__ scores3,
+                                                               int32_t* __restrict__ ids3) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    int k0 = 0, k1 = 0, k2 = 0;
+    for (int r = 0; r < R; ++r) {
+        const size_t base = 3 * ((size_t)r * N + i);
+        for (int j = 0; j < 3; ++j) {
+            const float c = scores_all[base + j];
+            const int kf = ids_all[base + j];
+            const bool first = s0 < c;
+            const bool second = (s0 > c) && (s1 < c);
+            const bool third = (s1 > c) && (s2 < c);
+            if (first) { s2 = s1; s1 = s0; s0 = c; k2 = k1; k1 = k0; k0 = kf; }
+            if (second) { s2 = s1; s1 = c; k2 = k1; k1 = kf; }
+            if (third) { s2 = c; k2 = kf; }
+        }
+    }
+    scores3[3 * i] = s0; scores3[3 * i + 1] = s1; scores3[3 * i + 2] = s2;
+    ids3[3 * i] = k0; ids3[3 * i + 1] = k1; ids3[3 * i + 2] = k2;
+}
+
 // pose tables: old_w2c, new_c2w [K,12] (3x4 row major), dq [K,4] (w,x,y,z) = rotation of
 // new_c2w * old_w2c, scale [K]
 __global__ __launch_bounds__(256) void splat_reanchor_kernel(
@@ -118,6 +148,18 @@ extern "C" int vings_splat_top3_update_gated(int N, const float* cur_importance,
     ProfScope prof(PROF_GLUE, (hipStream_t)stream);
     splat_top3_update_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(N, cur_importance, kf_id,
                                                                             scores3, kfids3, gate, gate_min);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
+}
+
+extern "C" int vings_splat_top3_merge(int N, int R, const float* scores_all, const int32_t* kfids_all,
+                                      float* scores3, int32_t* kfids3, void* stream) {
+    VINGS_REQUIRE(N >= 0 && R >= 1, "sizes");
+    if (N == 0) return VINGS_OK;
+    VINGS_REQUIRE(scores_all && kfids_all && scores3 && kfids3, "null pointer");
+    ProfScope prof(PROF_GLUE, (hipStream_t)stream);
+    splat_top3_merge_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(N, R, scores_all, kfids_all,
+                                                                           scores3, kfids3);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }

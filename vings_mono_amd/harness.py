@@ -369,11 +369,13 @@ class SurfelMapper:
             self._fb = fb
         return self._fb
 
-    def fused_view(self, settings, intr, gt, Rw2c_host, kf_id=0, reducer=None):
+    def fused_view(self, settings, intr, gt, Rw2c_host, kf_id=0, reducer=None, lean=None):
         """The same view step as backward_view + finish_view with no PyTorch op in it:
         activations, rasteriser forward, loss, rasteriser backward, chain rule + score
         weighting + bookkeeping, sparse Adam — about 22 HIP launches through the C ABI.
-        `settings` is the view's GaussianRasterizationSettings (see `view_settings`)."""
+        `settings` is the view's GaussianRasterizationSettings (see `view_settings`).
+        `lean=False` forces the full blend passes (median depth and flow planes, which the
+        mapping loss never reads) where the default takes the lean ones."""
         from . import _lib, surfel
         L = _lib.lib()
         self._match_reducer(reducer)
@@ -386,7 +388,7 @@ class SurfelMapper:
             xyz, rgb = P["_xyz"].detach(), P["_rgb"].detach()
             dgeom = torch.empty((max(n, 1), surfel.GRAD_STRIDE), dtype=torch.float32, device=dev)
             # (the loss has no term in the median depth or the flow: the lean blend passes)
-            lean = settings.u2_minus_u1 is None
+            lean = settings.u2_minus_u1 is None and (lean is None or lean)
             st, aux = surfel.rasterize_forward(
                 xyz, rgb, fb["opac"], fb["scales"], fb["rot"], settings,
                 raw=(P["_opacity"].detach(), P["_scaling"].detach(), P["_rotation"].detach()),

@@ -228,12 +228,39 @@ def add_new_frame(mapper, frame, accum_thresh, n_points=40000, max_radius=25, pe
     return n_pruned, n_added
 
 
-def rectify_tracker(mapper, c2w_list, intr, dense_maps, coarse_maps):
+def _keyframe_block(K, reducer):
+    """(first, count, rows per rank) of the calling rank's contiguous block of K keyframes."""
+    if reducer is None or reducer.comm_world() == 1:
+        return 0, K, K
+    per = -(-K // reducer.comm_world())
+    first = min(K, reducer.rank() * per)
+    return first, min(K, first + per) - first, per
+
+
+def _gather_blocks(reducer, maps, first, count, per):
+    """All ranks end up with every rank's rows of maps [K, ...] (rank r owns rows r*per ...)."""
+    K = maps.shape[0]
+    if K == per * reducer.comm_world():
+        reducer.all_gather(maps, maps[first:first + per])
+        return
+    padded = torch.zeros((per * reducer.comm_world(),) + tuple(maps.shape[1:]), dtype=maps.dtype,
+                         device=maps.device)
+    mine = torch.zeros((per,) + tuple(maps.shape[1:]), dtype=maps.dtype, device=maps.device)
+    mine[:count] = maps[first:first + count]
+    reducer.all_gather(padded, mine)
+    maps.copy_(padded[:K])
+
+
+def rectify_tracker(mapper, c2w_list, intr, dense_maps, coarse_maps, reducer=None):
     """Tracker-side refresh after a loop closure (loop_rectify.py:415-426): for every corrected
     keyframe pose render the depth and fold it into the tracker's stored maps.
     dense_maps [K,H,W] is updated in place where the rendered depth is positive; coarse_maps
     [K,H/8,W/8] receives the mean of the four centre pixels of every 8x8 block.  Both live on
-    the device here (the reference keeps them on the host and copies every render back)."""
+    the device here (the reference keeps them on the host and copies every render back).
+
+    With a `reducer` of more than one rank (every rank holds the same map and calls this with
+    the same arguments) the K renders are dealt out in contiguous blocks and the refreshed maps
+    gathered, so every replica of the tracker's buffers ends up with all of them."""
     from . import harness
     L = _lib.lib()
     dev = mapper.device
@@ -247,14 +274,18 @@ def rectify_tracker(mapper, c2w_list, intr, dense_maps, coarse_maps):
         # read here), its tiles taken longest list first
         act = synth.activate({k: v.detach() for k, v in mapper.params.items()})
         args = [act[k].contiguous() for k in ("means3D", "colors", "opacities", "scales", "rotations")]
-        for k, c2w in enumerate(c2w_list):
-            w2c = torch.linalg.inv(c2w.to(dev).float())
+        first, count, per = _keyframe_block(K, reducer)
+        for k in range(first, first + count):
+            w2c = torch.linalg.inv(c2w_list[k].to(dev).float())
             st, _ = surfel.rasterize_forward(*args, harness.view_settings(w2c, intr), keep_keys=False,
                                              lean=True, order_tiles=True)
             allmap = st.allmap
             _lib.check(L.vings_depth_refresh(H, W, _lib.ptr(allmap[0]), _lib.ptr(allmap[1]),
                                              _lib.ptr(dense_maps[k]), _lib.ptr(coarse_maps[k]),
                                              _lib.stream_ptr(dev)), "vings_depth_refresh")
+        if count != K:
+            _gather_blocks(reducer, dense_maps, first, count, per)
+            _gather_blocks(reducer, coarse_maps, first, count, per)
 
 
 def add_splats(mapper, new_params):
@@ -289,13 +320,21 @@ def add_splats(mapper, new_params):
     return mapper.n
 
 
-def calc_score(mapper, c2w_list, kf_ids, intr):
+def calc_score(mapper, c2w_list, kf_ids, intr, reducer=None):
     """Top-3 keyframes of every splat by blend-weight mass (loop_model.py:169-214): returns
     (scores [N,3] descending, kf ids [N,3] int32).  One forward-only importance pass per
-    keyframe; a view whose render would stay below 0.1 everywhere is skipped like there."""
+    keyframe; a view whose render would stay below 0.1 everywhere is skipped like there.
+
+    With a `reducer` of more than one rank (every rank holds the same map and calls this with
+    the same arguments) the keyframes are dealt out in contiguous blocks, every rank scores its
+    block, and the gathered records are merged by vings_splat_top3_merge into exactly what the
+    pass over all keyframes leaves."""
     from .harness import view_settings
     L = _lib.lib()
     dev, n = mapper.device, mapper.n
+    first, count, _ = _keyframe_block(len(c2w_list), reducer)
+    sharded = count != len(c2w_list)
+    c2w_list, kf_ids = c2w_list[first:first + count], kf_ids[first:first + count]
     scores3 = torch.zeros((n, 3), dtype=torch.float32, device=dev)
     ids3 = torch.zeros((n, 3), dtype=torch.int32, device=dev)
     cur = torch.empty(n, dtype=torch.float32, device=dev)
@@ -312,6 +351,16 @@ def calc_score(mapper, c2w_list, kf_ids, intr):
             _lib.check(L.vings_splat_top3_update_gated(
                 n, _lib.ptr(cur), int(kf), _lib.ptr(scores3), _lib.ptr(ids3), _lib.ptr(rgb_max), 0.1,
                 _lib.stream_ptr(dev)), "vings_splat_top3_update_gated")
+        if sharded:
+            R = reducer.comm_world()
+            all_s = torch.empty((R * n, 3), dtype=torch.float32, device=dev)
+            all_i = torch.empty((R * n, 3), dtype=torch.int32, device=dev)
+            reducer.all_gather(all_s, scores3)
+            reducer.all_gather(all_i, ids3)
+            scores3, ids3 = torch.empty_like(scores3), torch.empty_like(ids3)
+            _lib.check(L.vings_splat_top3_merge(n, R, _lib.ptr(all_s), _lib.ptr(all_i),
+                                                _lib.ptr(scores3), _lib.ptr(ids3),
+                                                _lib.stream_ptr(dev)), "vings_splat_top3_merge")
     return scores3, ids3
 
 

@@ -202,6 +202,28 @@ class GradReducer:
             return self._Done() if async_op else None
         return dist.all_reduce(t, op=op, group=self.group, async_op=async_op)
 
+    def rank(self):
+        import torch.distributed as dist
+        return dist.get_rank(self.group) if self.world > 1 else 0
+
+    def comm_world(self):
+        """Ranks of the communicator itself (a rehearsal may drive the exchange of `world`
+        ranks over a communicator of one)."""
+        import torch.distributed as dist
+        return dist.get_world_size(self.group) if self.world > 1 and dist.is_initialized() else 1
+
+    def all_gather(self, out, local):
+        """out [world * rows, ...] <- the `local` [rows, ...] of every rank, rank-major (local may
+        be the calling rank's own slice of out).  gloo takes host memory, staged here like
+        `_all_reduce` does."""
+        import torch.distributed as dist
+        if out.is_cuda and dist.get_backend(self.group) == "gloo":
+            h = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(h, local.cpu(), group=self.group)
+            out.copy_(h)
+            return
+        dist.all_gather_into_tensor(out, local, group=self.group)
+
     def all_reduce_packed(self):
         """SUM over `fbuf`, already filled on the device (the fused view step packs it with one
         kernel)."""

@@ -93,6 +93,68 @@ def make_splats(n, W, H, n_views=1, seed=SEED_BASE, z_range=(1.5, 60.0)):
             "_scaling": scaling.contiguous(), "_rotation": rotation.contiguous()}
 
 
+def _quat_z_to(normal):
+    """Unit quaternions (w,x,y,z) that turn the splat's local +z axis into `normal` [n,3]."""
+    nx, ny, nz = normal.unbind(1)
+    q = torch.stack([1.0 + nz, -ny, nx, torch.zeros_like(nx)], 1)
+    flip = (1.0 + nz) < 1e-6                      # normal = -z: half a turn about x
+    q[flip] = torch.tensor([0.0, 1.0, 0.0, 0.0])
+    return torch.nn.functional.normalize(q)
+
+
+def make_surface_splats(n, W, H, n_views=1, seed=SEED_BASE, z_far=80.0):
+    """A street instead of a cloud: opaque splats lying ON surfaces (a ground plane 1.6 m under
+    the cameras, two side walls, three facades across the street at 12 / 25 / 45 m), the way
+    a converged map looks.  Opacity ~ sigmoid(N(2.2, 0.7)) ~ 0.9, so the lists of a tile end
+    early on the first surface; the ground near the horizon and the walls far down the street
+    pile many splats into few tiles, so list lengths spread by more than an order of magnitude
+    and the longest exceed the 2048-entry LDS sort.  Same dict as `make_splats`."""
+    g = torch.Generator().manual_seed(seed)
+    intr = intrinsic_for(W, H)
+    fx = intr["fv"]
+    c2w = window_poses(n_views)
+    kind = torch.rand(n, generator=g)
+    k = torch.randint(0, n_views, (n,), generator=g)
+    u = (torch.rand(n, generator=g) * 1.1 - 0.05) * W
+    v = (torch.rand(n, generator=g) * 1.1 - 0.05) * H
+    lz0, lz1 = math.log(1.5), math.log(z_far)
+    z = torch.exp(torch.rand(n, generator=g) * (lz1 - lz0) + lz0)
+    cam_h, wall_x, wall_top = 1.6, 6.0, -5.0
+    xs = (u - (W - 1) / 2.0) / fx
+    ys = (v - (H - 1) / 2.0) / fx
+    ground = kind < 0.40
+    wall = (kind >= 0.40) & (kind < 0.70)
+    facade = kind >= 0.70
+    xc = torch.zeros(n, 3)
+    normal = torch.zeros(n, 3)
+    # ground: the pixel column and the distance are drawn, the height is the plane's
+    xc[ground] = torch.stack([xs * z, torch.full((n,), cam_h), z], 1)[ground]
+    normal[ground] = torch.tensor([0.0, -1.0, 0.0])
+    # walls: left / right, the height drawn between the ground and the eaves
+    side = torch.where(torch.rand(n, generator=g) < 0.5, -1.0, 1.0)
+    yw = wall_top + torch.rand(n, generator=g) * (cam_h - wall_top)
+    xc[wall] = torch.stack([side * wall_x, yw, z], 1)[wall]
+    normal[wall] = torch.stack([-side, torch.zeros(n), torch.zeros(n)], 1)[wall]
+    # facades: fronto-parallel planes across part of the street
+    fz = torch.tensor([12.0, 25.0, 45.0])[torch.randint(0, 3, (n,), generator=g)]
+    fx0 = torch.where(fz == 12.0, -6.0, torch.where(fz == 25.0, -1.0, -6.0))
+    fx1 = torch.where(fz == 12.0, -2.5, torch.where(fz == 25.0, 6.0, 6.0))
+    xf = fx0 + torch.rand(n, generator=g) * (fx1 - fx0)
+    xc[facade] = torch.stack([xf, yw, fz], 1)[facade]
+    normal[facade] = torch.tensor([0.0, 0.0, -1.0])
+    dist = xc[:, 2].clone()
+    Rk, tk = c2w[k, :3, :3], c2w[k, :3, 3]
+    xyz = torch.einsum("nij,nj->ni", Rk, xc) + tk
+    normal = torch.einsum("nij,nj->ni", Rk, normal)
+    r_px = torch.exp(torch.randn(n, 2, generator=g) * 0.6 + math.log(2.5))
+    scaling = torch.log(dist[:, None] * r_px / fx)
+    rotation = _quat_z_to(normal) + torch.randn(n, 4, generator=g) * 0.03
+    opacity = torch.randn(n, 1, generator=g) * 0.7 + 2.2
+    rgb = torch.rand(n, 3, generator=g)
+    return {"_xyz": xyz.contiguous(), "_rgb": rgb.contiguous(), "_opacity": opacity.contiguous(),
+            "_scaling": scaling.contiguous(), "_rotation": rotation.contiguous()}
+
+
 def perturb_splats(params, seed=SEED_BASE + 1):
     """Copy used to render ground-truth images: xyz += N(0,0.01), rgb += N(0,0.05)."""
     g = torch.Generator().manual_seed(seed)
