@@ -375,7 +375,7 @@ def main():
         barrier()
         return round(n_views_total * n_steps / (time.perf_counter() - t), 3)
 
-    reference_api = reference_binning = graph_replay = autograd_api = full_passes = None
+    reference_api = reference_binning = graph_replay = autograd_api = full_passes = stable_half = None
     if args.rehearse_rccl:
         args.no_side_runs = True
     if world == 1 and not args.no_side_runs and not args.no_graph_run and loop is None \
@@ -392,6 +392,22 @@ def main():
         # fused HIP kernels behind a differentiable scalar) instead of the PyTorch loss graph
         autograd_api = side_run(autograd=True, torch_loss=False)
         full_passes = side_run(full_passes=True)
+        # half of the map under the stable mask (no optimiser step for those splats,
+        # gaussian_base.py:400-402): the backward pass skips their gradients
+        mapper.stable_mask[:] = torch.rand(mapper.n, generator=torch.Generator().manual_seed(9)).to(dev) < 0.5
+        mapper.note_stable_mask()
+        stable_half = {"value": side_run()}
+        profiling.select(["blend_bwd"])
+        profiling.enable(True)
+        step()
+        barrier()
+        pr = profiling.read().get("blend_bwd")
+        profiling.select(None)
+        profiling.enable(False)
+        if pr and pr["count"]:
+            stable_half["blend_bwd_ms"] = round(pr["ms"] / pr["count"], 4)
+        mapper.stable_mask.zero_()
+        mapper.note_stable_mask()
         if args.binning == "tight":
             surfel.set_tight_binning(False)
             reference_binning = side_run()
@@ -485,6 +501,11 @@ def main():
                 "value": full_passes, "unit": "frames/s",
                 "what": "the fused step with the full blend passes (median depth and flow planes "
                         "computed) instead of the lean ones"},
+            "stable_half": None if stable_half is None else dict(
+                stable_half, unit="frames/s",
+                what="the fused step with a random half of the splats under the stable mask: they "
+                     "keep their place in the compositing and their scores, the backward pass "
+                     "skips their gradient components and the optimiser their rows"),
             "graph_replay": None if graph_replay is None else {
                 "value": graph_replay, "unit": "frames/s",
                 "what": "the same fused step with every view replayed from a HIP graph captured "

@@ -330,6 +330,21 @@ int vings_surfel_blend_backward_accumulate_ordered(
     const float* geom, const float* bg, const uint8_t* pixel_mask, const float* final_T,
     const uint32_t* n_contrib, const float* dL_dcolor, const float* dL_dallmap, float* dgeom,
     const uint32_t* tile_order, void* stream);
+/* The same backward pass for a map with splats the optimiser will not step: stable_mask[N]
+ * (uint8, the mapper's _stable_mask; gaussian_base.py:400-402 zeroes their radii before
+ * SparseGaussianAdam.step(radii > 0, N), so their gradients are never read, while
+ * gaussian_model.py:163-168 records their scores like everybody's).  A flagged splat keeps its
+ * place in the compositing of the pixels behind it and its two score sums (components 18, 19 of
+ * its dgeom row); components 0..17 of its row stay as the caller cleared them.  Rows of
+ * unflagged splats are what vings_surfel_blend_backward_accumulate_ordered leaves, up to the
+ * order of the float atomics.  tile_order may be NULL; stable_mask NULL = no splat flagged.
+ * vings_surfel_project_backward_finish given the same mask turns a flagged row into zero
+ * gradients + recorded scores without reading components 0..17. */
+int vings_surfel_blend_backward_accumulate_stable(
+    int lean, int N, int H, int W, const uint32_t* ranges, const uint32_t* vals_sorted,
+    const float* geom, const float* bg, const uint8_t* pixel_mask, const float* final_T,
+    const uint32_t* n_contrib, const float* dL_dcolor, const float* dL_dallmap, float* dgeom,
+    const uint32_t* tile_order, const uint8_t* stable_mask, void* stream);
 int vings_surfel_blend_importance_ordered(int N, int H, int W, const uint32_t* ranges,
                                           const uint32_t* vals_sorted, const float* geom,
                                           const uint8_t* pixel_mask, float* importance,

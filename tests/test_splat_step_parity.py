@@ -151,10 +151,53 @@ def test_fused_view_matches_autograd_view():
     close(a.globalkf_max_scores, b.globalkf_max_scores, "kf_max", tol=1e-4)
 
 
+def test_fused_view_with_half_the_map_stable():
+    """Half of the splats under the stable mask: the view step that skips their gradients
+    (stable_skip) against the one that computes and then ignores them.  Same parameters, Adam
+    moments and score records (to what two runs of the float-atomic backward differ by); the
+    stable splats themselves do not move at all."""
+    dev = torch.device(DEV)
+    W, H = 160, 96
+    raw = synth.make_splats(5000, W, H, n_views=3, seed=23)
+    intr = synth.intrinsic_for(W, H)
+    c2w = synth.window_poses(3)
+    gtp = {k: v.to(dev) for k, v in synth.perturb_splats(raw).items()}
+    a, b = harness.SurfelMapper(raw, dev), harness.SurfelMapper(raw, dev)
+    flagged = torch.rand(5000, generator=torch.Generator().manual_seed(4)).to(dev) < 0.5
+    for m in (a, b):
+        m.stable_mask[:] = flagged
+    assert b.note_stable_mask() and not a.stable_skip
+    for k in range(3):
+        w2c = torch.linalg.inv(c2w[k]).to(dev)
+        with torch.no_grad():
+            pr = harness.render(gtp, w2c, intr)
+        gt = {"rgb": pr["rgb"].clone(), "depth": pr["depth"].clone(), "depth_cov": torch.ones_like(pr["depth"])}
+        for m in (a, b):
+            m.fused_view(harness.view_settings(w2c, intr), intr, gt, w2c[:3, :3].cpu(), k)
+    torch.cuda.synchronize()
+
+    def close(x, y, name, tol):
+        scale = float(x.abs().max())
+        assert float((x - y).abs().max()) <= tol * scale + 1e-12, name
+
+    for k in a.NAMES:
+        assert torch.equal(b.params[k].detach()[flagged], raw[k].to(dev)[flagged]), k
+        assert float((a.params[k].detach() - raw[k].to(dev)).abs().max()) > 0
+        close(a.params[k].detach() - raw[k].to(dev), b.params[k].detach() - raw[k].to(dev), k, 2e-2)
+        close(a.optimizer.state[a.params[k]]["exp_avg"], b.optimizer.state[b.params[k]]["exp_avg"], k, 2e-3)
+    close(a.global_scores, b.global_scores, "global_scores", 1e-5)
+    close(a.local_scores, b.local_scores, "local_scores", 1e-5)
+    close(a.globalkf_max_scores, b.globalkf_max_scores, "kf_max", 1e-5)
+    assert float(b.local_scores[flagged].abs().max()) > 0
+    assert float((a.globalkf_id == b.globalkf_id).float().mean()) >= 0.999
+
+
 @pytest.mark.parametrize("bookkeeping", [1, 0])
 def test_project_backward_finish_equals_the_two_calls(bookkeeping):
     """vings_surfel_project_backward_finish against vings_surfel_project_backward followed by
-    vings_splat_grad_finish on the same blend-pass output: every output bit-identical."""
+    vings_splat_grad_finish on the same blend-pass output: every output bit-identical, except
+    that the fused call leaves zeros where the two calls leave the (never read) gradients of
+    stable splats."""
     from vings_mono_amd import surfel
     dev = torch.device(DEV)
     L = _lib.lib()
@@ -203,7 +246,11 @@ def test_project_backward_finish_equals_the_two_calls(bookkeeping):
         5, bookkeeping, *[p(t) for t in out_b], p(cur_b), None, None, stream), "project_backward_finish")
     torch.cuda.synchronize()
     assert float(out_a[0].abs().max()) > 0 and int(out_a[5].sum()) > 0
-    for x, y in zip(out_a + rec_a + [cur], out_b + rec_b + [cur_b]):
+    flagged = stable.bool()
+    for x, y in zip(out_a[:5], out_b[:5]):
+        assert torch.equal(x[~flagged], y[~flagged])
+        assert float(x[flagged].abs().max()) > 0 and float(y[flagged].abs().max()) == 0
+    for x, y in zip(out_a[5:] + rec_a + [cur], out_b[5:] + rec_b + [cur_b]):
         assert torch.equal(x, y)
     # scores_grad is optional
     _lib.check(L.vings_surfel_project_backward_finish(
@@ -225,7 +272,9 @@ def test_project_backward_finish_equals_the_two_calls(bookkeeping):
             None, None, None, None, None, None, None, p(pk_b), p(keys_b), stream),
             "project_backward_finish (packed)")
         torch.cuda.synchronize()
-        assert torch.equal(pk_a, pk_b) and torch.equal(keys_a, keys_b)
+        assert torch.equal(pk_a[:, ~flagged], pk_b[:, ~flagged]) and torch.equal(keys_a, keys_b)
+        assert torch.equal(pk_a[13:, flagged], pk_b[13:, flagged])        # score and visibility columns
+        assert float(pk_b[:13, flagged].abs().max()) == 0
         assert not torch.equal(keys_a, keys0)
 
 

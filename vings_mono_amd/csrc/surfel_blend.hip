@@ -126,11 +126,12 @@ __device__ __forceinline__ void stage_batch(float4* __restrict__ lds,
                                             const float* __restrict__ geom,
                                             const uint32_t* __restrict__ vals, uint32_t idx,
                                             uint32_t end, uint32_t* __restrict__ ids, float tx0,
-                                            float ty0) {
+                                            float ty0, const uint8_t* __restrict__ stable = nullptr) {
     uint32_t mask = 0;
     if (idx < end) {
         const uint32_t id = vals[idx];
-        if (ids) ids[threadIdx.x] = id;
+        // (stable: the splat's "no optimiser step" flag rides in the top bit of its staged id)
+        if (ids) ids[threadIdx.x] = (stable && stable[id]) ? (id | 0x80000000u) : id;
         const float4* src = reinterpret_cast<const float4*>(geom + (size_t)id * VINGS_GEOM_STRIDE);
         float4 r[kRec4];
 #pragma unroll
@@ -362,14 +363,22 @@ __global__ __launch_bounds__(256, 6) void blend_importance_kernel(
 // backward
 // ---------------------------------------------------------------------------
 
-template <bool kLean>   // kLean: dL/dallmap[5], [7], [8] are zero and not read (see blend_fwd_kernel)
+// kLean: dL/dallmap[5], [7], [8] are zero and not read (see blend_fwd_kernel).
+// kStable: `stable` [N] flags the splats the optimiser will not step (the mapper's stable mask,
+// /root/reference/scripts/gaussian/gaussian_base.py:400-402: their radii are zeroed before
+// SparseGaussianAdam.step, so their gradients are never read).  Such a splat still takes part
+// in the compositing recurrence of the pixels behind it and still collects its two scores
+// (gaussian_model.py:163-168 records them for every splat), but the eighteen gradient
+// components, their algebra and their reduction are skipped: a wave-uniform branch, since a
+// splat is the same for every lane.
+template <bool kLean, bool kStable = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void blend_bwd_kernel(
     int H, int W, int gx, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ vals,
     const float* __restrict__ geom, const float* __restrict__ bg,
     const uint8_t* __restrict__ pixel_mask, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_dallmap, float* __restrict__ dgeom,
-    const uint32_t* __restrict__ tile_order) {
+    const uint32_t* __restrict__ tile_order, const uint8_t* __restrict__ stable) {
     __shared__ float4 rec[kBatchBwd * (kRec4 - 1)];
     __shared__ uint32_t ids[kBatchBwd];
     __shared__ unsigned long long hit[16];
@@ -480,7 +489,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
         const int cnt = (int)min((uint32_t)kBatchBwd, maxlast - bstart);
         __syncthreads();  // previous batch fully flushed
         stage_batch(rec, hit, geom, vals, r0 + bstart + threadIdx.x, r0 + bstart + cnt, ids,
-                    (float)(tx * 16), (float)(ty * 16));
+                    (float)(tx * 16), (float)(ty * 16), kStable ? stable : nullptr);
         __syncthreads();
         // the four ballot words of this wave's block, back to front (plain nested loops: see
         // blend_fwd_kernel)
@@ -528,6 +537,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
             S += s.n[0] * gN0 + s.n[1] * gN1 + s.n[2] * gN2;
             S += depth * gD;
             const float Bn = fmaf(last_alpha, S_last - B, B);
+            if (kStable && (__builtin_amdgcn_readfirstlane(ids[j]) >> 31)) {
+                // no optimiser step for this splat: the recurrence goes on, the two scores are
+                // summed over the wave (lower half: the blend weight, upper half: the weight
+                // times |dL/dcolour|), and that is all
+                B = c ? Bn : B;
+                S_last = c ? S : S_last;
+                last_alpha = c ? alpha : last_alpha;
+                float v = swap32_add(w, w * gabs);
+                v = half_row_sum(v);
+                v += dpp_f<0x140>(v);            // row_mirror: sum of the 16-lane row
+                v = swap16_add(v, v);
+                if ((lane & 31) == 0)
+                    atomicAdd(&dgeom[(size_t)(ids[j] & 0x7fffffffu) * kGrad + 18 + (lane >> 5)], v);
+                continue;
+            }
             const float dL_dalpha = c ? (S - Bn) * T - r_one_m * Tbg : 0.f;
             B = c ? Bn : B;
             S_last = c ? S : S_last;
@@ -623,7 +647,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
                     fetch_from, __builtin_bit_cast(int, v)));
                 // (dL/dTu = -dk and dL/dTv = -dl: the sign of components 0..5)
                 if (lane < kGrad)
-                    atomicAdd(&dgeom[(size_t)ids[j] * kGrad + lane], mine * flush_sign);
+                    atomicAdd(&dgeom[(size_t)(kStable ? ids[j] & 0x7fffffffu : ids[j]) * kGrad + lane],
+                              mine * flush_sign);
             }
           }
         }
@@ -680,7 +705,8 @@ static int blend_backward_impl(bool clear, bool lean, int N, int H, int W, const
                                            const float* final_T, const uint32_t* n_contrib,
                                            const float* dL_dcolor, const float* dL_dallmap,
                                            float* dgeom, void* stream,
-                                           const uint32_t* tile_order = nullptr) {
+                                           const uint32_t* tile_order = nullptr,
+                                           const uint8_t* stable = nullptr) {
     VINGS_REQUIRE(N >= 0 && H > 0 && W > 0, "sizes");
     if (N == 0) return VINGS_OK;
     VINGS_REQUIRE(ranges && bg && final_T && n_contrib && dL_dcolor && dL_dallmap && dgeom,
@@ -690,14 +716,22 @@ static int blend_backward_impl(bool clear, bool lean, int N, int H, int W, const
         VINGS_CHECK_HIP(hipMemsetAsync(dgeom, 0, sizeof(float) * (size_t)N * VINGS_GRAD_STRIDE, s));
     const int gx = (W + 15) / 16, gy = (H + 15) / 16;
     ProfScope prof(PROF_BLEND_BWD, s);
-    if (lean)
+    if (stable && lean)
+        blend_bwd_kernel<true, true><<<gx * gy, 256, 0, s>>>(H, W, gx, ranges, vals_sorted, geom, bg,
+                                                             pixel_mask, final_T, n_contrib, dL_dcolor,
+                                                             dL_dallmap, dgeom, tile_order, stable);
+    else if (stable)
+        blend_bwd_kernel<false, true><<<gx * gy, 256, 0, s>>>(H, W, gx, ranges, vals_sorted, geom, bg,
+                                                              pixel_mask, final_T, n_contrib, dL_dcolor,
+                                                              dL_dallmap, dgeom, tile_order, stable);
+    else if (lean)
         blend_bwd_kernel<true><<<gx * gy, 256, 0, s>>>(H, W, gx, ranges, vals_sorted, geom, bg,
                                                        pixel_mask, final_T, n_contrib, dL_dcolor,
-                                                       dL_dallmap, dgeom, tile_order);
+                                                       dL_dallmap, dgeom, tile_order, nullptr);
     else
         blend_bwd_kernel<false><<<gx * gy, 256, 0, s>>>(H, W, gx, ranges, vals_sorted, geom, bg,
                                                         pixel_mask, final_T, n_contrib, dL_dcolor,
-                                                        dL_dallmap, dgeom, tile_order);
+                                                        dL_dallmap, dgeom, tile_order, nullptr);
     VINGS_LAUNCH_CHECK();
     return VINGS_OK;
 }
@@ -787,4 +821,14 @@ extern "C" int vings_surfel_blend_backward_accumulate_ordered(
     const uint32_t* tile_order, void* stream) {
     return blend_backward_impl(false, lean != 0, N, H, W, ranges, vals_sorted, geom, bg, pixel_mask,
                                final_T, n_contrib, dL_dcolor, dL_dallmap, dgeom, stream, tile_order);
+}
+
+extern "C" int vings_surfel_blend_backward_accumulate_stable(
+    int lean, int N, int H, int W, const uint32_t* ranges, const uint32_t* vals_sorted,
+    const float* geom, const float* bg, const uint8_t* pixel_mask, const float* final_T,
+    const uint32_t* n_contrib, const float* dL_dcolor, const float* dL_dallmap, float* dgeom,
+    const uint32_t* tile_order, const uint8_t* stable_mask, void* stream) {
+    return blend_backward_impl(false, lean != 0, N, H, W, ranges, vals_sorted, geom, bg, pixel_mask,
+                               final_T, n_contrib, dL_dcolor, dL_dallmap, dgeom, stream, tile_order,
+                               stable_mask);
 }

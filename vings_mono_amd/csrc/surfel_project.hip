@@ -387,10 +387,14 @@ __device__ __forceinline__ void splat_backward(
     int i, int H, int W, float scale_mod, const float* __restrict__ means3D,
     const float* __restrict__ scales, const float* __restrict__ rots,
     const float* __restrict__ view, const float* __restrict__ proj, int radii_i,
-    const float* __restrict__ dgeom, SplatGrad& o) {
+    const float* __restrict__ dgeom, SplatGrad& o, bool scores_only = false) {
     float dm[3] = {0, 0, 0}, ds[2] = {0, 0}, dq[4] = {0, 0, 0, 0};
     float dop = 0, dc[3] = {0, 0, 0}, dxy[2] = {0, 0}, sc[2] = {0, 0};
-    if (radii_i > 0) {
+    if (radii_i > 0 && scores_only) {
+        // a splat the optimiser will not step: its two scores are all anybody reads
+        const float4 g4v = reinterpret_cast<const float4*>(dgeom + (size_t)i * VINGS_GRAD_STRIDE)[4];
+        sc[0] = g4v.z; sc[1] = g4v.w;
+    } else if (radii_i > 0) {
         const float4* g4 = reinterpret_cast<const float4*>(dgeom + (size_t)i * VINGS_GRAD_STRIDE);
         const float4 g0 = g4[0], g1 = g4[1], g2 = g4[2], g3 = g4[3], g4v = g4[4];
         float dA[3][3] = {{g0.x, g0.y, g0.z}, {g0.w, g1.x, g1.y}, {g1.z, g1.w, g2.x}};
@@ -497,7 +501,10 @@ __global__ __launch_bounds__(256) void project_bwd_finish_kernel(
     // incomplete, so nothing of this step may reach the records or the parameters
     if (guard_count && *guard_count > guard_limit) return;
     SplatGrad g;
-    splat_backward(i, H, W, scale_mod, means3D, a.scales, rots, view, proj, a.radii[i], dgeom, g);
+    // (stable splats: gaussian_base.py:400-402 keeps them out of the optimiser step, so their
+    // gradients come out as zeros here without the chain behind them; the scores are recorded)
+    splat_backward(i, H, W, scale_mod, means3D, a.scales, rots, view, proj, a.radii[i], dgeom, g,
+                   a.stable_mask && a.stable_mask[i]);
     if (scores) reinterpret_cast<float2*>(scores)[i] = make_float2(g.sc[0], g.sc[1]);
     splat_finish(i, a, g.dm, g.dc, g.dop, make_float2(g.ds[0], g.ds[1]),
                  make_float4(g.dq[0], g.dq[1], g.dq[2], g.dq[3]), g.sc[0], g.sc[1]);

@@ -249,6 +249,16 @@ class SurfelMapper:
         self.globalkf_id = z(n, dt=torch.int64)
         self.globalkf_max_scores = z(n)
         self.last_loss = None
+        # True once the stable mask holds any splat (maintenance.stablemask_control keeps it; a
+        # caller that edits stable_mask by hand calls note_stable_mask): the fused view step
+        # then takes the backward pass that skips the gradients of stable splats.  Only a
+        # choice between two kernels that give the optimiser the same rows.
+        self.stable_skip = False
+
+    def note_stable_mask(self):
+        """Call after editing `stable_mask` directly (one host read of a device flag)."""
+        self.stable_skip = bool(self.stable_mask.any())
+        return self.stable_skip
 
     def render(self, w2c, intr, scores=None):
         return render(self.params, w2c, intr, scores=scores)
@@ -403,7 +413,8 @@ class SurfelMapper:
                                                          self.loss_weights, cache=True)
             g = fb["grads"]
             view, proj = aux[0], aux[1]
-            surfel.blend_backward(st, aux, d_rgb, d_allmap, dgeom=dgeom, lean=lean)
+            surfel.blend_backward(st, aux, d_rgb, d_allmap, dgeom=dgeom, lean=lean,
+                                  stable=self.stable_mask if self.stable_skip else None)
             if compact:
                 self._exchange_compact(L, reducer, st, xyz, fb, view, proj, dgeom, kf_id, stream)
             else:
@@ -457,7 +468,8 @@ class SurfelMapper:
             g = fb["grads"]
             view, proj = aux[0], aux[1]
             surfel.blend_backward(st, aux, d_rgb, d_allmap, dgeom=dgeom,
-                                  lean=settings.u2_minus_u1 is None)
+                                  lean=settings.u2_minus_u1 is None,
+                                  stable=self.stable_mask if self.stable_skip else None)
             count_ptr = st.tail_ptr + 8                    # third count word: D
             _lib.check(L.vings_surfel_project_backward_finish_guarded(
                 n, st.H, st.W, 1.0, ptr(xyz), ptr(fb["scales"]), ptr(fb["rot"]), ptr(view),
@@ -480,7 +492,7 @@ class SurfelMapper:
         """Everything a captured view step has baked in by address: a change (map maintenance
         replaces the parameter and moment arrays, a new keyframe brings new images) makes the
         graph stale."""
-        sig = [self.n]
+        sig = [self.n, self.stable_skip]
         for k in self.NAMES:
             p = self.params[k]
             st = self.optimizer.state.get(p, {})

@@ -432,3 +432,5 @@ def stablemask_control(mapper):
     to_unstable = (loc[:, 1] > 0.3) & (loc[:, 0] > 0.05) & mapper.stable_mask
     mapper.stable_mask[to_unstable] = False
     mapper.local_scores.mul_(0.0)
+    if hasattr(mapper, "note_stable_mask"):
+        mapper.note_stable_mask()

@@ -333,17 +333,32 @@ def rasterize_forward_fixed(means3D, colors, opacities, scales, rotations, setti
     return st, (view, proj, bg, mask, flow)
 
 
-def blend_backward(st, aux, g_color, g_allmap, dgeom=None, lean=False):
+def blend_backward(st, aux, g_color, g_allmap, dgeom=None, lean=False, stable=None):
     """Pixel half of the backward pass: the per-splat accumulator rows dgeom [N, GRAD_STRIDE]
     that vings_surfel_project_backward (or its fused _finish form) turns into gradients.
     `dgeom`: rows already cleared by the forward pass (rasterize_forward(dgeom=...)); the pass
-    then adds into them instead of clearing a fresh array."""
+    then adds into them instead of clearing a fresh array.
+    `stable` ([N] uint8 / bool, needs dgeom): splats the optimiser will not step; they keep
+    their place in the compositing and their two scores, their gradient components stay zero
+    (vings_surfel_blend_backward_accumulate_stable)."""
     L = _lib.lib()
     _, _, bg, mask, _ = aux
     N, H, W = st.N, st.H, st.W
     dev = st.geom.device
     if lean and dgeom is None:
         raise _lib.VingsError("the lean backward pass adds into rows the forward pass cleared: pass dgeom")
+    if stable is not None:
+        if dgeom is None:
+            raise _lib.VingsError("the stable-splat backward pass adds into cleared rows: pass dgeom")
+        _lib.require_gpu_tensor(stable, "stable")
+        if stable.numel() != N or stable.element_size() != 1:
+            raise _lib.VingsError("stable must hold N one-byte flags")
+        check(L.vings_surfel_blend_backward_accumulate_stable(
+            1 if lean else 0, N, H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg), ptr(mask),
+            ptr(st.final_T), ptr(st.n_contrib), ptr(g_color), ptr(g_allmap), ptr(dgeom),
+            ptr(st.tile_order), ptr(stable.view(torch.uint8)), stream_ptr(dev)),
+            "vings_surfel_blend_backward_accumulate_stable")
+        return dgeom
     if dgeom is not None and st.tile_order is not None:
         check(L.vings_surfel_blend_backward_accumulate_ordered(
             1 if lean else 0, N, H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg), ptr(mask),
