@@ -472,8 +472,13 @@ int vings_splat_compact_apply(int N, const int32_t* dst_index, int n_arrays,
  * VINGS_ERR_ARG.  The number of kept rows is written to the DEVICE word n_keep_device on the
  * stream.  dst_index is what vings_splat_compact_plan produces.  All calls on one GPU share
  * that GPU's scratch array: calls that overlap in time on one GPU (two streams, two threads)
- * race; calls on one stream do not. */
+ * race; calls on one stream do not.
+ * The first call on a GPU looks up the address of that GPU's array (hipGetSymbolAddress, not a
+ * stream operation).  A caller that records the call into a HIP graph does that lookup before
+ * the capture begins with vings_splat_compact_static_prepare() (current device; idempotent;
+ * allocates nothing) or with one ordinary call. */
 int vings_splat_compact_static_max_rows(void);
+int vings_splat_compact_static_prepare(void);
 int vings_splat_compact_plan_static(int N, const uint8_t* keep, int32_t* dst_index,
                                     int64_t* n_keep_device, void* stream);
 
@@ -694,7 +699,13 @@ int vings_frame_distance(const float* poses, const float* disps, const float* in
  * bilinear lookup of a (2r+1)^2 window around coords[E,2,h1,w1] in
  * volume[E,h1,w1,h2,w2] -> corr[E,2r+1,2r+1,h1,w1]; backward scatters
  * corr_grad into volume_grad (zeroed by the call).  half != 0: volume and
- * corr are float16 (the reference runs this under autocast). */
+ * corr are float16 (the reference runs this under autocast).
+ * Channel convention: corr[e,i,j,y,x] is the bilinear sample of volume[e,y,x,:,:] at
+ * (coords.x + i - r, coords.y + j - r) -- the X offset is the SLOW index, the Y offset the fast
+ * one, as in the public DROID-SLAM kernels the reference's extension descends from.  The
+ * update operator's pretrained weights (droid.pth) convolve over these 4 * 49 channels
+ * (modules/corr.py:46-50), so the order is part of the contract; the extension's source is not
+ * in the reference tree, so the order is restated from that upstream layout, not pinned. */
 int vings_corr_index_forward(const void* volume, const float* coords, void* corr, int E, int h1,
                              int w1, int h2, int w2, int r, int half, void* stream);
 int vings_corr_index_backward(const float* coords, const void* corr_grad, void* volume_grad, int E,
@@ -704,7 +715,8 @@ int vings_corr_index_backward(const float* coords, const void* corr_grad, void* 
  * corr.py:106-125): the same window without the all-pairs volume.
  *   fmap1[B,H,W,C], fmap2[B,H2,W2,C] float32 (channels last, as corr.py:102 permutes them),
  *   coords[B,S,H,W,2] = (x, y) in fmap2 pixels, corr[B,S,(2r+1)^2,H,W].
- * corr[b,s,i*(2r+1)+j,h,w] = bilinear sample at (x + j - r, y + i - r) of
+ * corr[b,s,i*(2r+1)+j,h,w] = bilinear sample at (x + i - r, y + j - r) (X offset slow, the
+ * channel convention of vings_corr_index_forward) of
  * (yy, xx) -> <fmap1[b,h,w,:], fmap2[b,yy,xx,:]>, zero outside fmap2: equal to
  * vings_corr_index_forward on volume = fmap1 . fmap2^T.  C a multiple of 4, <= 512; r <= 7.
  * backward: fmap1_grad, fmap2_grad (same shapes as the maps, zeroed by the call) receive the

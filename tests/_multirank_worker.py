@@ -63,6 +63,25 @@ def main():
     for m, r in ((a, red), (b, red), (c, red_c), (d, red_d)):  # ... and the overlapped form at the end
         fin = m.sync_records(r, async_op=True)
         fin()
+    # Checkpoints of a multi-rank job.  The records were merged just above, so one rank alone
+    # may save without a collective; after one more view step the keys are unmerged again: a
+    # save without the reducer is refused, with it (all ranks call) it merges first.
+    from vings_mono_amd import io_formats
+    if rank == 0:
+        io_formats.save_pt_ckpt(b, out_path + ".merged.ckpt")
+    b.fused_view(harness.view_settings(w2c, intr), intr, gt, w2c[:3, :3].cpu(), k, red)
+    a.finish_view(*a.backward_view(w2c, intr, gt), k, red)       # (the other mappers take the step too)
+    c.fused_view(harness.view_settings(w2c, intr), intr, gt, w2c[:3, :3].cpu(), k, red_c)
+    d.fused_view(harness.view_settings(w2c, intr), intr, gt, w2c[:3, :3].cpu(), k, red_d)
+    try:
+        io_formats.save_pt_ckpt(b, out_path + ".refused.ckpt")
+        refused = False
+    except ValueError:
+        refused = True
+    io_formats.save_pt_ckpt(b, out_path + f".rank{rank}.ckpt", red)
+    a.sync_records(red)
+    c.sync_records(red_c)
+    d.sync_records(red_d)
     # GPU side of a loop closure over 7 keyframes (not a multiple of 2 or 4: the last rank's
     # block is short or empty): scoring and tracker refresh dealt out over the ranks against the
     # same calls on this rank alone
@@ -77,7 +96,7 @@ def main():
         maintenance.rectify_tracker(b, kf_c2w, intr, dense, coarse, r_)
         maps.append((dense, coarse))
     torch.cuda.synchronize()
-    state = {"rank": rank, "exchanged_rows": exchanged,
+    state = {"rank": rank, "exchanged_rows": exchanged, "unmerged_save_refused": refused,
              "loop": {"scores_err": float(((s_one - s_all).abs() / (s_one.abs() + 1e-3)).max()),
                       "ids_match": float((i_one == i_all).float().mean()),
                       "dense_equal": bool(torch.equal(maps[0][0], maps[1][0])),

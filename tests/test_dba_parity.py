@@ -342,6 +342,30 @@ def test_altcorr_backward_parity(case):
     assert gc.shape == co.shape and float(gc.abs().max()) == 0.0
 
 
+def test_window_channel_order_one_hot_on_the_gpu():
+    """The hand-computed asymmetric fixture of tests/test_oracle_dba.py through both lookups: a
+    target two pixels to the right lights up channel (r + 2) * 7 + r = 38 and nothing else."""
+    from test_oracle_dba import one_hot_window_case
+    from vings_mono_amd import dba
+    vol, coords, (y, x), channel = one_hot_window_case()
+    dev = torch.device("cuda:0")
+    for dt in (torch.float32, torch.float16):
+        (out,) = dba.corr_index_forward(torch.from_numpy(vol).to(dev, dt),
+                                        torch.from_numpy(coords).float().to(dev), 3)
+        win = out.float().reshape(49, *vol.shape[1:3])[:, y, x].cpu().numpy()
+        assert np.nonzero(win)[0].tolist() == [channel] and win[channel] == 1.0
+    f1 = torch.zeros((1, 9, 11, 16), device=dev); f2 = torch.zeros((1, 9, 11, 16), device=dev)
+    f1[0, y, x, 2] = 1.0
+    f2[0, y, x + 2, 2] = 1.0
+    co = torch.from_numpy(np.moveaxis(coords, 1, -1)[:, None].copy()).float().to(dev)
+    (alt,) = dba.altcorr_forward(f1, f2, co, 3)
+    win = alt[0, 0, :, y, x].cpu().numpy()
+    assert np.nonzero(win)[0].tolist() == [channel] and win[channel] == 1.0
+    # the general-radius kernels follow the same order
+    (out2,) = dba.corr_index_forward(torch.from_numpy(vol).float().to(dev), torch.from_numpy(coords).float().to(dev), 2)
+    assert np.nonzero(out2.reshape(25, *vol.shape[1:3])[:, y, x].cpu().numpy())[0].tolist() == [4 * 5 + 2]
+
+
 def test_altcorr_equals_volume_lookup_on_the_gpu():
     """altcorr_forward and corr_index_forward(all-pairs volume) are two routes to one window."""
     from vings_mono_amd import dba

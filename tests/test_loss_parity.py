@@ -126,6 +126,29 @@ def test_ground_truth_cache_gives_the_same_bits(H, W):
     assert gt["_loss_cache"][0] != tag
     for x, y in zip(want, got):
         assert torch.equal(x, y)
+    # a NEW tensor at the OLD address: the entry keeps the old image alive, so the allocator
+    # cannot hand its address out; forcing the case by writing the new image into the old
+    # tensor's storage in place must refill as well (version counter)
+    tag = gt["_loss_cache"][0]
+    gt["rgb"].copy_(gt["rgb"].flip(1))
+    want = harness.mapping_loss_hip(*renders[1], {k: gt[k] for k in ("rgb", "depth", "depth_cov")},
+                                    w2c[:3, :3], intr, WEIGHTS)
+    got = harness.mapping_loss_hip(*renders[1], gt, w2c[:3, :3], intr, WEIGHTS, cache=True)
+    assert gt["_loss_cache"][0] != tag and gt["_loss_cache"][0][:2] == tag[:2]   # same addresses
+    for x, y in zip(want, got):
+        assert torch.equal(x, y)
+    # the caller's pattern the tag alone could not catch: drop the image, allocate another of
+    # the same size (the caching allocator would return the freed block) -- the entry's own
+    # reference keeps the block taken, so the new image gets another address and refills
+    old_ptr = gt["rgb"].data_ptr()
+    gt["rgb"] = None
+    gt["rgb"] = renders[2][0].clone()
+    assert gt["rgb"].data_ptr() != old_ptr
+    want = harness.mapping_loss_hip(*renders[0], {k: gt[k] for k in ("rgb", "depth", "depth_cov")},
+                                    w2c[:3, :3], intr, WEIGHTS)
+    got = harness.mapping_loss_hip(*renders[0], gt, w2c[:3, :3], intr, WEIGHTS, cache=True)
+    for x, y in zip(want, got):
+        assert torch.equal(x, y)
 
 
 def test_no_sky_no_valid_masks_do_not_divide_by_zero():

@@ -38,6 +38,14 @@ def test_multi_rank_view_steps(tmp_path, world):
             for k in names + ("global_scores", "local_scores", "kf_id", "kf_max"):
                 assert torch.equal(s0[impl][k], s1[impl][k]), f"{impl}: replicas 0 and {r} differ in {k}"
         assert s1["exchanged_rows"] == s0["exchanged_rows"]
+    # checkpoints: rank 0 alone saved the merged map; an unmerged one was refused without the
+    # reducer and, with it, every rank wrote the same records
+    assert os.path.exists(out + ".merged.ckpt") and not os.path.exists(out + ".refused.ckpt")
+    ck = [torch.load(out + f".rank{r}.ckpt", weights_only=True) for r in range(world)]
+    for r in range(world):
+        assert torch.load(out + f".rank{r}.pt", weights_only=True)["unmerged_save_refused"]
+        for key in ("_xyz", "_global_scores", "_local_scores", "_globalkf_id", "_globalkf_max_scores"):
+            assert torch.equal(ck[0][key], ck[r][key]), key
     # loop closure dealt out over the ranks = the same calls on one rank: the depth maps bit for
     # bit; the scores to what two runs of the importance pass differ by (its per-tile partial
     # sums meet in float atomics; the merge itself is checked bit-exact in

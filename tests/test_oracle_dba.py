@@ -187,14 +187,41 @@ def test_corr_index_bilinear_and_adjoint():
     assert out.shape == (E, 3, 3, h, w)
     e = 1
     np.testing.assert_allclose(out[e, 1, 1], vol[e, yy, xx, yy, xx])
-    np.testing.assert_allclose(out[e, 1, 2, :, :-1], vol[e, yy, xx, yy, np.minimum(xx + 1, w - 1)][:, :-1])
-    assert np.all(out[e, 0, :, 0, :] == 0)   # window rows above the map are zero
+    # X offset is the slow window index: element (2, 1) looks one pixel to the RIGHT
+    np.testing.assert_allclose(out[e, 2, 1, :, :-1], vol[e, yy, xx, yy, np.minimum(xx + 1, w - 1)][:, :-1])
+    assert np.all(out[e, :, 0, 0, :] == 0)   # window entries above the map (Y offset -1 in row 0) are zero
     # adjoint identity <A v, g> = <v, A^T g> at random sub-pixel coordinates
     coords = coords + rng.uniform(-1.5, 1.5, size=coords.shape)
     g = rng.normal(size=(E, 3, 3, h, w))
     lhs = (O.corr_index_forward(vol, coords, 1) * g).sum()
     rhs = (vol * O.corr_index_backward(vol.shape, coords, g, 1)).sum()
     np.testing.assert_allclose(lhs, rhs, rtol=1e-10)
+
+
+def one_hot_window_case(r=3, h=9, w=11, y=4, x=3):
+    """A hand-computed asymmetric fixture for the window's channel order: the only non-zero
+    correlation of source pixel (y, x) is with target pixel (y, x + 2), and the pixel looks at
+    its own position.  Offset (+2, 0) must light up window element (i, j) = (r + 2, r), i.e.
+    channel (r + 2) * (2r + 1) + r = 38 for r = 3 (X offset slow), and nothing else."""
+    vol = np.zeros((1, h, w, h, w))
+    vol[0, y, x, y, x + 2] = 1.0
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    coords = np.stack([xx, yy])[None].astype(float)
+    return vol, coords, (y, x), (r + 2) * (2 * r + 1) + r
+
+
+def test_window_channel_order_one_hot():
+    vol, coords, (y, x), channel = one_hot_window_case()
+    assert channel == 38
+    out = O.corr_index_forward(vol, coords, 3).reshape(1, 49, *vol.shape[1:3])
+    lit = np.nonzero(out[0, :, y, x])[0]
+    assert lit.tolist() == [channel] and out[0, channel, y, x] == 1.0
+    # the on-the-fly form on feature maps whose only correlated pair is that same one
+    f1 = np.zeros((1, 9, 11, 4)); f2 = np.zeros((1, 9, 11, 4))
+    f1[0, y, x, 2] = 1.0
+    f2[0, y, x + 2, 2] = 1.0
+    alt = O.altcorr_forward(f1, f2, np.moveaxis(coords, 1, -1)[:, None], 3)    # [B,S,49,H,W]
+    assert np.nonzero(alt[0, 0, :, y, x])[0].tolist() == [channel]
 
 
 # ---------------------------------------------------------------------------

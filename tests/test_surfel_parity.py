@@ -623,6 +623,43 @@ def test_two_threads_render_on_one_gpu():
     assert not errors, errors
 
 
+def test_more_threads_than_mailbox_slots():
+    """Twenty host threads render on one GPU: more than the sixteen mailbox slots, so some share
+    one.  A thread whose mailbox was taken over by another's launch before it waited still gets
+    ITS view's instance count (stamped mailboxes, device copy as the fallback)."""
+    import threading
+    if not surfel.SPECULATE:
+        pytest.skip("needs the launch / wait split")
+    dev = torch.device("cuda:0")
+    jobs = [(synth.make_splats(3000 + 700 * k, 192, 128, n_views=2, seed=90 + k), 192, 128) for k in range(4)]
+    want = [_forward_state(raw, W, H) for raw, W, H in jobs]
+    assert len({w.D for w in want}) == 4
+    torch.cuda.synchronize()
+    errors = []
+    start = threading.Barrier(20)
+
+    def work(t):
+        try:
+            k = t % 4
+            raw, W, H = jobs[k]
+            with torch.cuda.stream(torch.cuda.Stream(dev)):
+                start.wait()
+                for _ in range(6):
+                    got = _forward_state(raw, W, H)
+                    torch.cuda.current_stream().synchronize()
+                    assert got.D == want[k].D, (t, got.D, want[k].D)
+                    assert torch.equal(got.color, want[k].color) and torch.equal(got.ranges, want[k].ranges)
+        except Exception as exc:            # noqa: BLE001 - reported by the main thread
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(20)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+
+
 def test_lean_blend_passes_equal_the_full_ones():
     """The blend passes of the mapper's view step (no median depth, no flow) against the full
     passes: forward planes bit-identical apart from the three planes written as zeros; the

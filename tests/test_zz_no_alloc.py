@@ -50,6 +50,39 @@ def test_static_plan_matches_workspace_plan_twice():
         assert bool((dst[keep.numel():] == -7).all())          # nothing written past N
 
 
+def test_static_plan_allocates_nothing_and_can_be_captured():
+    """Device memory (the driver's free-byte count and torch's own books) is the same before
+    and after the calls; and the call recorded into a HIP graph -- the scratch address looked up
+    beforehand with vings_splat_compact_static_prepare -- replays on new mask contents."""
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    masks = [(torch.rand(300_007, generator=g) > t).to(torch.uint8).to(dev) for t in (0.2, 0.7, 0.5)]
+    keep = masks[0].clone()
+    dst = torch.empty(keep.numel(), dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    _lib.check(L.vings_splat_compact_static_prepare(), "prepare")
+    wants = [_plan_with_workspace(m) for m in masks]
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(dev)
+    alloc0, reserved0 = torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev)
+    for _ in range(3):
+        _plan_static(keep, dst, count)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(dev)[0] == free0
+    assert (torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev)) == (alloc0, reserved0)
+    assert int(count.item()) == wants[0][1] and torch.equal(dst, wants[0][0])
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        _plan_static(keep, dst, count)
+    for m, (want_dst, want_m) in zip(masks[1:], wants[1:]):
+        keep.copy_(m)
+        dst.fill_(-7)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert int(count.item()) == want_m and torch.equal(dst, want_dst)
+
+
 def test_static_plan_edges():
     L = _lib.lib()
     dev = torch.device("cuda:0")

@@ -63,6 +63,7 @@ _SIGNATURES = {
                                             _c.POINTER(_c.c_int64), _P]),
     "vings_splat_compact_apply": (_c.c_int, [_c.c_int, _P, _c.c_int, _P, _P, _P, _P]),
     "vings_splat_compact_static_max_rows": (_c.c_int, []),
+    "vings_splat_compact_static_prepare": (_c.c_int, []),
     "vings_splat_compact_plan_static": (_c.c_int, [_c.c_int, _P, _P, _P, _P]),
     "vings_knn3_mean_dist2": (_c.c_int, [_c.c_int, _P, _P, _P]),
     "vings_keyframe_backproject": (_c.c_int, [_c.c_int] * 3 + [_P] * 3 + [_c.POINTER(_c.c_float)] +

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void corr_index_fwd_kernel(
             const float right0 = fetch(yi, xi + 1), right1 = fetch(yi + 1, xi + 1);
             const float v = (1.f - dx) * (1.f - dy) * left0 + dx * (1.f - dy) * right0 +
                             (1.f - dx) * dy * left1 + dx * dy * right1;
-            from_f(corr[(((size_t)e * rd + i) * rd + j) * plane + (size_t)y * w1 + x], v);
+            from_f(corr[(((size_t)e * rd + j) * rd + i) * plane + (size_t)y * w1 + x], v);   // x offset: the slow index
             left0 = right0; left1 = right1;
         }
     }
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void corr_index_fwd_r3_kernel(
             const float dxp = dxs[q], dyp = dys[q];
             const float o = (1.f - dxp) * (1.f - dyp) * v[q] + dxp * (1.f - dyp) * right +
                             (1.f - dxp) * dyp * down + dxp * dyp * dright;
-            if (pi < rd && pj < rd && p0 + q < npix) from_f(out_s[wv][pi * rd + pj][p0 + q], o);
+            if (pi < rd && pj < rd && p0 + q < npix) from_f(out_s[wv][pj * rd + pi][p0 + q], o);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void corr_index_bwd_kernel(
     };
     for (int i = 0; i < rd; ++i)
         for (int j = 0; j < rd; ++j) {
-            const float g = to_f(corr_grad[(((size_t)e * rd + i) * rd + j) * plane + (size_t)y * w1 + x]);
+            const float g = to_f(corr_grad[(((size_t)e * rd + j) * rd + i) * plane + (size_t)y * w1 + x]);
             const int yi = y0 + i - r, xi = x0 + j - r;
             push(yi, xi, (1.f - dx) * (1.f - dy) * g);
             push(yi, xi + 1, dx * (1.f - dy) * g);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void altcorr_fwd_kernel(
                     w11 = dx * dy;
         const float* d = dots + wv * P;
         for (int k = lane; k < K; k += 64) {
-            const int i = k / rd, j = k - i * rd;
+            const int j = k / rd, i = k - j * rd;     // channel = x offset * rd + y offset
             const float* e = d + i * n1 + j;
             tile[k * kAltPx + p] = w00 * e[0] + w01 * e[1] + w10 * e[n1] + w11 * e[n1 + 1];
         }
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void altcorr_fwd_tile_kernel(
             const int sub = o / K, k = o - sub * K;
             const int pi = wv * kAltTW + st * 4 + sub;
             const float dx = fdx[pi], dy = fdy[pi];
-            const int i = k / rd, j = k - i * rd;
+            const int j = k / rd, i = k - j * rd;     // channel = x offset * rd + y offset
             const float* e = d4 + sub * 64 + i * n1 + j;
             tile[k * kAltTile + pi] = (1.f - dx) * (1.f - dy) * e[0] + dx * (1.f - dy) * e[1] +
                                       (1.f - dx) * dy * e[n1] + dx * dy * e[n1 + 1];
@@ -528,10 +528,10 @@ __global__ __launch_bounds__(256) void altcorr_bwd_kernel(
     for (int q = lane; q < P; q += 64) {
         const int iy = q / n1, ix = q - iy * n1;
         float v = 0.f;
-        if (iy < rd && ix < rd) v += w00 * g[(size_t)(iy * rd + ix) * plane];
-        if (iy < rd && ix > 0) v += w01 * g[(size_t)(iy * rd + ix - 1) * plane];
-        if (iy > 0 && ix < rd) v += w10 * g[(size_t)((iy - 1) * rd + ix) * plane];
-        if (iy > 0 && ix > 0) v += w11 * g[(size_t)((iy - 1) * rd + ix - 1) * plane];
+        if (iy < rd && ix < rd) v += w00 * g[(size_t)(ix * rd + iy) * plane];
+        if (iy < rd && ix > 0) v += w01 * g[(size_t)((ix - 1) * rd + iy) * plane];
+        if (iy > 0 && ix < rd) v += w10 * g[(size_t)(ix * rd + iy - 1) * plane];
+        if (iy > 0 && ix > 0) v += w11 * g[(size_t)((ix - 1) * rd + iy - 1) * plane];
         gpos[q] = v;
     }
     __builtin_amdgcn_wave_barrier();     // the wave's own LDS writes, read back below in order

@@ -169,6 +169,25 @@ uint32_t* g_scratch_ptr[kMaxDev] = {};
 
 extern "C" int vings_splat_compact_static_max_rows(void) { return kStaticMaxRows; }
 
+// Address of the current GPU's copy of the scratch array, looked up once per device with that
+// device current.
+static int static_scratch(uint32_t** out) {
+    int dev = 0;
+    VINGS_CHECK_HIP(hipGetDevice(&dev));
+    VINGS_REQUIRE(dev >= 0 && dev < kMaxDev, "device index");
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev])
+        VINGS_CHECK_HIP(hipGetSymbolAddress((void**)&g_scratch_ptr[dev], HIP_SYMBOL(g_compact_scratch)));
+    *out = g_scratch_ptr[dev];
+    VINGS_REQUIRE(*out != nullptr, "scratch address");
+    return VINGS_OK;
+}
+
+extern "C" int vings_splat_compact_static_prepare(void) {
+    uint32_t* p = nullptr;
+    return static_scratch(&p);
+}
+
 extern "C" int vings_splat_compact_plan_static(int N, const uint8_t* keep, int32_t* dst_index,
                                                int64_t* n_keep_device, void* stream) {
     VINGS_REQUIRE(N >= 0, "sizes");
@@ -177,19 +196,12 @@ extern "C" int vings_splat_compact_plan_static(int N, const uint8_t* keep, int32
                   "use vings_splat_compact_plan with a workspace");
     VINGS_REQUIRE(n_keep_device, "null pointer");
     hipStream_t s = (hipStream_t)stream;
-    int dev = 0;
-    VINGS_CHECK_HIP(hipGetDevice(&dev));
-    VINGS_REQUIRE(dev >= 0 && dev < kMaxDev, "device index");
     uint32_t* counts = nullptr;
-    {
-        // the address of this GPU's copy of the scratch array, looked up once per device with
-        // that device current
-        std::lock_guard<std::mutex> lk(g_scratch_mu);
-        if (!g_scratch_ptr[dev])
-            VINGS_CHECK_HIP(hipGetSymbolAddress((void**)&g_scratch_ptr[dev], HIP_SYMBOL(g_compact_scratch)));
-        counts = g_scratch_ptr[dev];
-    }
-    VINGS_REQUIRE(counts != nullptr, "scratch address");
+    // (the first call on a GPU looks the address up, which is not a stream operation: a caller
+    // that captures this call into a graph makes that first call, or
+    // vings_splat_compact_static_prepare, before the capture begins)
+    const int rc = static_scratch(&counts);
+    if (rc != VINGS_OK) return rc;
     if (N == 0) {
         // nothing to scan: the count word is still written, on the stream
         VINGS_CHECK_HIP(hipMemsetAsync(n_keep_device, 0, sizeof(int64_t), s));

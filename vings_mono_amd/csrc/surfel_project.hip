@@ -324,7 +324,8 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
 
 // Single workgroup: in-place exclusive scan of block_counts[0..nb), total in [nb].
 __global__ __launch_bounds__(1024) void scan_blocks_kernel(uint32_t* __restrict__ counts, int nb,
-                                                           uint32_t* __restrict__ host_tail) {
+                                                           uint32_t* __restrict__ host_tail,
+                                                           uint32_t generation = 0u) {
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
     if (threadIdx.x == 0) carry_s = 0;
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(uint32_t* __restrict_
         // the same three words straight into pinned host memory: the host reads them after
         // the stream has drained, without a copy command in between
         host_tail[0] = lo; host_tail[1] = hi; host_tail[2] = carry_s;
+        if (generation) host_tail[3] = generation;   // whose launch filled this mailbox
     }
 }
 
@@ -514,19 +516,29 @@ __global__ __launch_bounds__(256) void project_bwd_finish_kernel(
 // device-to-host copy costs ~50 us more per view.  Every GPU gets a ring of kMailSlots 64-byte
 // mailboxes with an event each, created at the first projection call on that GPU and kept for
 // the life of the process (the only memory this library owns besides the optional event pool).
-// Every launch takes the next slot of its GPU's ring and remembers it in the calling thread;
-// vings_surfel_project_wait reads the slot of the calling thread's latest launch.  So host
-// threads (or streams driven from different threads) that render on one GPU at the same time
-// do not see each other's counts; one thread may have kMailSlots launches in flight before a
-// slot is reused, although its wait() only ever returns the latest one.
+// A host thread takes a slot of its GPU's ring at its first launch there and keeps it: its
+// launches and its waits use that slot, so host threads (or streams driven from different
+// threads) that render on one GPU at the same time do not see each other's counts, however many
+// launches the others make in between.  Only when more than kMailSlots threads have rendered on
+// one GPU do two of them share a slot; every launch therefore stamps the mailbox with its own
+// generation number, and a wait() that finds another launch's stamp (or whose event was
+// re-recorded by the other thread) falls back to draining its own stream and copying the three
+// words from the device, where the launch left a second copy behind the block prefix.
+// wait() returns the calling thread's LATEST launch on the GPU.
 namespace {
 constexpr int kMaxDevices = 64;
 constexpr int kMailSlots = 16;
 std::mutex g_mail_mu[kMaxDevices];
 uint32_t* g_mail[kMaxDevices] = {};                      // kMailSlots * 16 words
 hipEvent_t g_mail_evt[kMaxDevices][kMailSlots] = {};
-std::atomic<unsigned> g_mail_next[kMaxDevices];
-thread_local int t_mail_dev = -1, t_mail_slot = -1;      // the calling thread's latest launch
+std::atomic<unsigned> g_mail_next[kMaxDevices];          // slots handed to threads so far
+std::atomic<unsigned> g_mail_gen[kMaxDevices];           // launches so far
+thread_local signed char t_slot_of_dev[kMaxDevices];     // this thread's slot per GPU, +1 (0 = none yet)
+// the calling thread's latest launch: GPU, slot, stamp, stream, device copy of the three words
+thread_local int t_mail_dev = -1, t_mail_slot = -1;
+thread_local uint32_t t_mail_gen = 0;
+thread_local hipStream_t t_mail_stream = nullptr;
+thread_local const uint32_t* t_mail_devcopy = nullptr;
 // 1: a splat is binned only into the tiles its alpha >= 1/255 box reaches (the default);
 // 0: into every tile of the reference's 3-sigma square (forward.cu preprocess / getRect).
 std::atomic<int> g_tight_binning{1};   // process default
@@ -566,7 +578,14 @@ static int project_launch(int N, int H, int W, float scale_modifier, const float
             g_mail[dev] = m;
         }
     }
-    const int slot = user_tail ? -1 : (int)(g_mail_next[dev].fetch_add(1u, std::memory_order_relaxed) % kMailSlots);
+    int slot = -1;
+    uint32_t gen = 0;
+    if (!user_tail) {
+        if (t_slot_of_dev[dev] == 0)
+            t_slot_of_dev[dev] = (signed char)(1 + g_mail_next[dev].fetch_add(1u, std::memory_order_relaxed) % kMailSlots);
+        slot = t_slot_of_dev[dev] - 1;
+        do gen = g_mail_gen[dev].fetch_add(1u, std::memory_order_relaxed) + 1u; while (gen == 0u);
+    }
     const int nb = cdiv(N, 256);
     const int tight = t_tight_binning >= 0 ? t_tight_binning
                                            : g_tight_binning.load(std::memory_order_relaxed);
@@ -592,11 +611,14 @@ static int project_launch(int N, int H, int W, float scale_modifier, const float
         *dev_out = dev;
         return VINGS_OK;
     }
-    scan_blocks_kernel<<<1, 1024, 0, s>>>(block_prefix, nb, g_mail[dev] + 16 * slot);
+    scan_blocks_kernel<<<1, 1024, 0, s>>>(block_prefix, nb, g_mail[dev] + 16 * slot, gen);
     VINGS_LAUNCH_CHECK();
     VINGS_CHECK_HIP(hipEventRecord(g_mail_evt[dev][slot], s));
     t_mail_dev = dev;
     t_mail_slot = slot;
+    t_mail_gen = gen;
+    t_mail_stream = s;
+    t_mail_devcopy = block_prefix + 3 * nb + 1;
     *dev_out = dev;
     return VINGS_OK;
 }
@@ -606,11 +628,18 @@ static int project_wait(int dev, int64_t* num_instances_host, uint32_t* depth_bi
                   "this thread has launched no projection on the current GPU");
     const int slot = t_mail_slot;
     VINGS_CHECK_HIP(hipEventSynchronize(g_mail_evt[dev][slot]));
-    volatile uint32_t* tail = g_mail[dev] + 16 * slot;   // depth-bit min, max, instance total
-    *num_instances_host = (int64_t)tail[2];
+    volatile uint32_t* tail = g_mail[dev] + 16 * slot;   // depth-bit min, max, instance total, stamp
+    uint32_t w[3] = {tail[0], tail[1], tail[2]};
+    if (tail[3] != t_mail_gen) {
+        // a thread sharing this slot launched in between: the mailbox (and perhaps the event)
+        // is theirs now; this thread's own words are still behind its block prefix
+        VINGS_CHECK_HIP(hipStreamSynchronize(t_mail_stream));
+        VINGS_CHECK_HIP(hipMemcpy(w, t_mail_devcopy, sizeof(w), hipMemcpyDeviceToHost));
+    }
+    *num_instances_host = (int64_t)w[2];
     if (depth_bits_range_host) {
-        depth_bits_range_host[0] = tail[2] > 0 ? tail[0] : 0u;
-        depth_bits_range_host[1] = tail[2] > 0 ? tail[1] : 0xFFFFFFFFu;
+        depth_bits_range_host[0] = w[2] > 0 ? w[0] : 0u;
+        depth_bits_range_host[1] = w[2] > 0 ? w[1] : 0xFFFFFFFFu;
     }
     return VINGS_OK;
 }

@@ -242,6 +242,11 @@ def _corr_args(volume, coords, radius):
 
 
 def corr_index_forward(volume, coords, radius):
+    """droid_backends.corr_index_forward (modules/corr.py:12): [corr] with corr[E,2r+1,2r+1,h1,w1].
+    Channel convention: corr[e,i,j,y,x] samples volume[e,y,x] at (coords.x + i - r,
+    coords.y + j - r): the X offset is the slow index (the layout of the public DROID-SLAM
+    kernels, which the update operator's pretrained weights expect; restated from there, the
+    reference tree holds nothing that pins it).  altcorr_forward uses the same order."""
     volume, coords, dims = _corr_args(volume, coords, radius)
     E, h1, w1, _, _, r, _ = dims
     rd = 2 * r + 1

@@ -153,8 +153,11 @@ def mapping_loss_hip(rgb, allmap, gt, Rw2c_host, intr, weights=DEFAULT_LOSS_WEIG
 
     cache=True keeps what depends on the ground truth alone (filtered moments of gt["rgb"],
     pixel classes, their counts) in gt["_loss_cache"] between calls, which is what the mapper
-    wants while it iterates over a keyframe.  The entry is tied to the addresses of gt["rgb"] /
-    gt["depth"]; a caller that overwrites those images IN PLACE drops it with
+    wants while it iterates over a keyframe.  The entry is tied to the two image tensors
+    themselves: it holds references to them (so their addresses cannot be handed to other
+    tensors while it lives) and remembers their version counters (so an in-place torch write
+    invalidates it); new tensors assigned to gt["rgb"] / gt["depth"] never match.  Only a write
+    through a raw pointer (a kernel of another library) escapes it: then drop the entry with
     `gt.pop("_loss_cache", None)`.  Same bits with and without.
     """
     from . import _lib
@@ -181,12 +184,16 @@ def mapping_loss_hip(rgb, allmap, gt, Rw2c_host, intr, weights=DEFAULT_LOSS_WEIG
             float(intr["cu"]), float(intr["cv"]), wts, _lib.ptr(d_rgb), _lib.ptr(d_allmap),
             _lib.ptr(loss_vec), _lib.ptr(ws), ws.numel())
     if cache:
-        tag = (gt_rgb.data_ptr(), gt_depth.data_ptr(), H, W)
+        tag = (gt_rgb.data_ptr(), gt_depth.data_ptr(), H, W, gt_rgb._version, gt_depth._version)
         ent = gt.get("_loss_cache")
-        valid = ent is not None and ent[0] == tag
+        valid = ent is not None and ent[0] == tag and ent[2] is gt_rgb and ent[3] is gt_depth
         if not valid:
-            ent = (tag, torch.empty(int(lib.vings_mapping_loss_gt_cache_bytes(H, W)),
-                                    dtype=torch.uint8, device=dev))
+            # (the buffer of a stale entry is reused when the size fits: a captured view step
+            # has its address baked in, see SurfelMapper._graph_signature)
+            nbytes = int(lib.vings_mapping_loss_gt_cache_bytes(H, W))
+            buf = ent[1] if ent is not None and ent[1].numel() == nbytes and ent[1].device == dev \
+                else torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            ent = (tag, buf, gt_rgb, gt_depth)
             gt["_loss_cache"] = ent
         _lib.check(lib.vings_mapping_loss_cached(*args, _lib.ptr(ent[1]), 1 if valid else 0,
                                                  _lib.stream_ptr(dev)), "vings_mapping_loss_cached")
@@ -305,6 +312,7 @@ class SurfelMapper:
             from . import parallel
             vis, s0_sum = reducer.reduce(grads, cur, vis)
             self._pending_keys = torch.maximum(self._record_keys(), parallel.record_keys(cur, kf_id))
+            self._records_dirty = True
             self.local_scores[:, 0] += s0_sum
             self.global_scores[:, 0] = (self.global_scores[:, 0] + s0_sum).clamp(0.0, 1e4)
         else:
@@ -338,6 +346,7 @@ class SurfelMapper:
         last sync_records; int64 [N,2]."""
         if getattr(self, "_pending_keys", None) is None:
             self._pending_keys = torch.zeros((self.n, 2), dtype=torch.int64, device=self.device)
+        self._records_dirty = True       # a view step is about to fold its scores in
         return self._pending_keys
 
     def sync_records(self, reducer, async_op=False):
@@ -348,7 +357,8 @@ class SurfelMapper:
         records are always current and this does nothing.  With async_op the collective is only
         started and a function that completes the merge is returned (None when there is nothing
         to do), so independent work can be queued in between."""
-        if reducer is None or reducer.world == 1 or getattr(self, "_pending_keys", None) is None:
+        if reducer is None or reducer.world == 1 or getattr(self, "_pending_keys", None) is None \
+                or not getattr(self, "_records_dirty", True):
             return None
         from . import _lib
         keys = self._pending_keys
@@ -361,6 +371,7 @@ class SurfelMapper:
                 self.n, _lib.ptr(keys), _lib.ptr(self.local_scores),
                 _lib.ptr(self.globalkf_max_scores), _lib.ptr(self.globalkf_id),
                 _lib.stream_ptr(self.device)), "vings_splat_merge_records")
+            self._records_dirty = False  # nothing unmerged until the next view step
 
         if async_op:
             return finish
@@ -500,6 +511,11 @@ class SurfelMapper:
         sig += [t.data_ptr() for t in (self.global_scores, self.local_scores, self.stable_mask,
                                        self.globalkf_id, self.globalkf_max_scores)]
         sig += [gt[k].data_ptr() for k in ("rgb", "depth", "depth_cov")]
+        # the loss kernels' per-keyframe cache: its address is baked in, and so is "the cache
+        # is valid", which only holds while the images are the tensors it was filled from
+        ent = gt.get("_loss_cache")
+        sig += [0 if ent is None else ent[1].data_ptr(), gt["rgb"]._version, gt["depth"]._version,
+                id(gt["rgb"]), id(gt["depth"])]
         sig += [settings.viewmatrix.data_ptr(), settings.projmatrix.data_ptr()]
         sig += [float(g["lr"]) for g in self.optimizer.param_groups]
         return tuple(sig)

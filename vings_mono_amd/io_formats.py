@@ -99,15 +99,22 @@ def save_pt_ckpt(mapper, path, reducer=None):
     """The reference's checkpoint dict from a harness.SurfelMapper.  The five parameter entries
     are nn.Parameters like the reference's own (gaussian_base.py:492-505): its load_pt_ckpt
     assigns them straight to the model and builds the optimiser on them, so plain tensors would
-    load with requires_grad=False and could not be trained further.  On a multi-rank job pass
-    the job's GradReducer: the score records of a rank are complete only after the record keys
-    have been merged over the ranks."""
-    if getattr(mapper, "_pending_keys", None) is not None:
+    load with requires_grad=False and could not be trained further.
+
+    Multi-rank jobs: the score records of a rank are complete only after the record keys the
+    view steps gathered have been merged over the ranks (SurfelMapper.sync_records, a
+    collective).  Two ways to save:
+      * every rank calls `mapper.sync_records(reducer)`, then ONE rank (or all) calls
+        save_pt_ckpt(mapper, path) -- no collective runs in here;
+      * every rank calls save_pt_ckpt(mapper, path_of_this_rank, reducer): the merge runs in
+        here, so ALL ranks must make the call (rank 0 alone would wait for the others forever).
+    A mapper with unmerged keys and no reducer is refused."""
+    if getattr(mapper, "_pending_keys", None) is not None and getattr(mapper, "_records_dirty", True):
         if reducer is None or reducer.world == 1:
-            raise ValueError("this mapper holds record keys not yet merged over the ranks: "
-                             "pass the job's GradReducer (or call sync_records first)")
+            raise ValueError("this mapper holds record keys not yet merged over the ranks: call "
+                             "mapper.sync_records(reducer) on every rank first, or pass the job's "
+                             "GradReducer here on every rank")
         mapper.sync_records(reducer)
-        mapper._pending_keys = None
     d = {k: torch.nn.Parameter(mapper.params[k].detach().clone()) for k in NAMES}
     d.update({ref: getattr(mapper, ours) for ref, ours in RECORDS.items()})
     torch.save(d, path)
