@@ -26,6 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+F64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix rate, AMD's data-sheet figure (256 CUs x 4 SIMDs x
+                               # 32 flop/clk x 2.4 GHz; v_mfma_f64_16x16x4_f64 = 2048 flop in 64 cycles)
 
 
 def parse():
@@ -57,6 +59,9 @@ def parse():
                     help="tight: a splat enters only the tiles its alpha >= 1/255 footprint "
                          "reaches (same rendered bits, shorter instance list); reference: the "
                          "3-sigma square of the reference's rasteriser (bit-exact instance list)")
+    ap.add_argument("--stable-frac", type=float, default=0.0,
+                    help="put this random share of the splats under the stable mask for the whole "
+                         "run (a side workload: the metric's map has none)")
     ap.add_argument("--no-side-runs", action="store_true",
                     help="skip the reference_api / reference_binning figures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -246,6 +251,9 @@ def main():
         assert c2w_rank.shape[0] == V, "views per GPU x GPUs must fit the 32-keyframe window"
     n_views_total = V * world
     mapper = harness.SurfelMapper(raw, dev)
+    if args.stable_frac > 0:
+        mapper.stable_mask[:] = torch.rand(mapper.n, generator=torch.Generator().manual_seed(9)).to(dev) < args.stable_frac
+        mapper.note_stable_mask()
     gt_mapper_params = {k: v.to(dev) for k, v in synth.perturb_splats(raw).items()}
     c2w_rank = c2w_rank.to(dev)
     my_views = list(range(rank * V, (rank + 1) * V))      # global keyframe ids
@@ -383,7 +391,8 @@ def main():
         step(graphed=True)          # eager: learns the instance counts
         step(graphed=True)          # captures one graph per keyframe
         graph_replay = side_run(n_steps=min(args.steps, 10), graphed=True)
-    if world == 1 and not args.no_side_runs and not (args.autograd or args.torch_loss) and loop is None:
+    if world == 1 and not args.no_side_runs and not (args.autograd or args.torch_loss) and loop is None \
+            and args.stable_frac == 0:
         # the reference's own call pattern (gaussian_base.py:367-403): PyTorch activations,
         # GaussianRasterizer through autograd, the PyTorch loss graph, loss.backward(), PyTorch
         # score bookkeeping, SparseGaussianAdam.step -- through the drop-in names
@@ -449,6 +458,43 @@ def main():
     if roof is not None:
         stage_ms["blend_bwd"] = roof["avg_kernel_ms"]     # the timed region's own figure
 
+    # ---- the dense-BA kernels on their own (inside the step they share the GPU with the view
+    # steps of the window, so their stage_ms there are not kernel times) ----
+    roof_dba = None
+    if dba is not None and rank == 0:
+        profiling.select(None)
+        profiling.enable(True)
+        for _ in range(5):
+            dba.run()
+        torch.cuda.synchronize()
+        pd = profiling.read()
+        profiling.enable(False)
+        ds = dba.describe()
+        ht, wd = (int(x) for x in ds["grid"].split("x"))
+        HWd, E, P, K = ht * wd, ds["edges"], ds["free_poses"], ds["depth_maps"]
+        per = lambda k: pd[k]["ms"] / max(pd[k]["count"], 1) if k in pd else None
+        t_lin, t_schur, t_solve, t_retr = per("dba_jacobian"), per("dba_schur"), per("dba_solve"), per("dba_retract")
+        if t_lin and t_schur:
+            lin_bytes = 76 * E * HWd                      # 20 B read + 56 B written per edge and pixel
+            schur_flop = 2 * (6 * P) ** 2 * K * HWd       # dense upper bound of E Q E^T
+            roof_dba = {
+                "linearize": {"bound": "hbm", "kernel": "dba_linearize_kernel",
+                              "achieved": round(lin_bytes / (t_lin * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": round(lin_bytes / (t_lin * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                              "avg_ms": round(t_lin, 4), "algorithmic_bytes": lin_bytes},
+                "schur": {"bound": "mfma", "kernel": "dba_schur_kernel", "dtype": "f64",
+                          "achieved": round(schur_flop / (t_schur * 1e-3) / 1e12, 3),
+                          "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(schur_flop / (t_schur * 1e-3) / 1e12 / F64_MATRIX_PEAK_TFLOPS, 5),
+                          "avg_ms": round(t_schur, 4), "algorithmic_flop": schur_flop},
+                "solve_ms": None if t_solve is None else round(t_solve, 4),
+                "retract_ms": None if t_retr is None else round(t_retr, 4),
+                "note": "per Gauss-Newton iteration, the bundle adjustment running alone on the GPU "
+                        "(HIP events around each stage); counter evidence for the same kernels "
+                        "(FETCH_SIZE / WRITE_SIZE, SQ_INSTS_VALU_MFMA_MOPS_F64, "
+                        "SQ_VALU_MFMA_BUSY_CYCLES) is under profiles/r3/dba_counters.txt; the f64 "
+                        "matrix peak is AMD's data-sheet figure"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and workload == "c3":
         from oracle import cpu_baseline
@@ -474,7 +520,7 @@ def main():
                                         ("" if loop is None else " + loop closure over %d keyframes "
                                          "per step (scoring and tracker refresh dealt out over the GPUs, "
                                          "re-anchor on every replica; pose-graph solve excluded)" % loop["K"]))),
-                       "scene": args.scene, "binning": args.binning,
+                       "scene": args.scene, "stable_frac": args.stable_frac, "binning": args.binning,
                        "blend": "lean (no median-depth / flow planes: the mapping loss has no term "
                                 "in them; full_passes = the drop-in rasteriser's passes)",
                        "view_step": "autograd" if (args.autograd or args.torch_loss) else "fused C-ABI sequence",
@@ -487,7 +533,7 @@ def main():
                            {"form": "planar", "rows": mapper.n} if reducer.last_exchanged_rows is None
                            else {"form": "compact", "chunks": args.exchange_chunks,
                                  "rows": reducer.last_exchanged_rows, "of": mapper.n})},
-            "roofline": roof, "cpu_baseline": cpu, "stage_ms": stage_ms,
+            "roofline": roof, "roofline_dba": roof_dba, "cpu_baseline": cpu, "stage_ms": stage_ms,
             "reference_api": None if reference_api is None else {
                 "value": reference_api, "unit": "frames/s",
                 "what": "same step through GaussianRasterizer autograd + PyTorch loss graph + "

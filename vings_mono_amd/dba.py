@@ -333,8 +333,10 @@ class BenchProblem:
         self.disps.clamp_(min=0.001)
 
     def describe(self):
+        import numpy as np
+        depth_maps = len(np.unique(np.concatenate((np.arange(self.t0, self.t1), self.np["ii"]))))
         return {"grid": f"{self.ht}x{self.wd}", "edges": self.E, "free_poses": self.t1 - self.t0,
-                "itrs": self.itrs, "lm": 1e-4, "ep": 0.1}
+                "depth_maps": int(depth_maps), "itrs": self.itrs, "lm": 1e-4, "ep": 0.1}
 
 
 def make_bench_problem(dev, ht, wd):
