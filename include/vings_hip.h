@@ -345,6 +345,20 @@ int vings_surfel_blend_backward_accumulate_stable(
     const float* geom, const float* bg, const uint8_t* pixel_mask, const float* final_T,
     const uint32_t* n_contrib, const float* dL_dcolor, const float* dL_dallmap, float* dgeom,
     const uint32_t* tile_order, const uint8_t* stable_mask, void* stream);
+/* The backward pass for a caller that does not know what its upstream gradient holds (the
+ * autograd wrapper of GaussianRasterizer, gaussian_base.py:382): for splats WITHOUT flow
+ * (u2_minus_u1 absent: the flow planes of dL_dallmap then multiply zeros) the lean pass is the
+ * full pass whenever dL_dallmap[5] (median depth) is identically zero, which is what every loss
+ * of the reference gives (loss_utils.py:110-153 has no term in it).  One small launch tests that
+ * plane into flag_word (a caller-owned device word), then the lean and the full pass are both
+ * launched and the one the flag does not select returns at its first instruction.  Adds into
+ * dgeom like vings_surfel_blend_backward_accumulate_ordered; tile_order may be NULL.  Do not use
+ * it with flow attached to the splats. */
+int vings_surfel_blend_backward_auto(
+    int N, int H, int W, const uint32_t* ranges, const uint32_t* vals_sorted, const float* geom,
+    const float* bg, const uint8_t* pixel_mask, const float* final_T, const uint32_t* n_contrib,
+    const float* dL_dcolor, const float* dL_dallmap, float* dgeom, const uint32_t* tile_order,
+    uint32_t* flag_word, void* stream);
 int vings_surfel_blend_importance_ordered(int N, int H, int W, const uint32_t* ranges,
                                           const uint32_t* vals_sorted, const float* geom,
                                           const uint8_t* pixel_mask, float* importance,

@@ -430,6 +430,39 @@ def test_which_splats_carry_the_gradient_error(oracle32, oracle64, tight):
     assert share_all <= 0.15 and share_bad >= 0.5 and share_bad >= 3.0 * share_all, (share_bad, share_all)
 
 
+@pytest.mark.parametrize("median_grad", [False, True])
+def test_auto_backward_equals_the_full_pass(median_grad):
+    """rasterize_backward without flow decides on the device between the lean and the full
+    blend pass (vings_surfel_blend_backward_auto): with a zero median-depth plane in the
+    upstream gradient the lean pass runs, with a non-zero one the full pass; either way the
+    rows equal those of the full pass, up to the order of the float atomics."""
+    dev = torch.device("cuda:0")
+    sc = scene(n=8000, W=320, H=192, scale_mul=2.0)
+    H, W, N = sc["H"], sc["W"], 8000
+    rng = np.random.default_rng(31)
+    gC = torch.from_numpy(rng.normal(size=(3, H, W)).astype(np.float32)).to(dev)
+    gA = rng.normal(size=(9, H, W)).astype(np.float32)
+    if not median_grad:
+        gA[5] = 0.0
+    gA = torch.from_numpy(gA).to(dev)
+    inp, st, aux = run_forward(sc, dev)
+    assert aux[4] is None
+    auto = surfel.blend_backward(st, aux, gC, gA)                       # the autograd wrapper's call
+    full = surfel.blend_backward(st, aux, gC, gA, dgeom=torch.zeros((N, surfel.GRAD_STRIDE), device=dev))
+    torch.cuda.synchronize()
+    a, f = auto.cpu().numpy().astype(np.float64), full.cpu().numpy().astype(np.float64)
+    assert np.abs(f).sum() > 0
+    for c in range(20):
+        err = np.sqrt(((a[:, c] - f[:, c]) ** 2).sum()) / max(np.sqrt((f[:, c] ** 2).sum()), 1e-30)
+        assert err <= 1e-5, (c, err)
+    if median_grad:
+        # the median plane does reach the gradients on this scene: the lean pass would differ
+        gA0 = gA.clone()
+        gA0[5] = 0.0
+        lean = surfel.blend_backward(st, aux, gC, gA0).cpu().numpy().astype(np.float64)
+        assert np.sqrt(((lean - f) ** 2).sum()) > 1e-3 * np.sqrt((f ** 2).sum())
+
+
 def test_autograd_module_api():
     """The drop-in module surface: keyword call, no_grad, means2D=None, scores.grad under a
     zero loss (/root/reference/scripts/loop/loop_model.py:185-186)."""

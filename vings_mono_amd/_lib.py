@@ -43,6 +43,7 @@ _SIGNATURES = {
     "vings_surfel_blend_forward_ordered": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int] + [_P] * 11),
     "vings_surfel_blend_backward_accumulate_ordered": (_c.c_int, [_c.c_int] * 4 + [_P] * 12),
     "vings_surfel_blend_backward_accumulate_stable": (_c.c_int, [_c.c_int] * 4 + [_P] * 13),
+    "vings_surfel_blend_backward_auto": (_c.c_int, [_c.c_int] * 3 + [_P] * 13),
     "vings_surfel_blend_backward": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int] + [_P] * 11),
     "vings_surfel_blend_backward_accumulate": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int] + [_P] * 11),
     "vings_surfel_project_backward": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float] +

@@ -378,11 +378,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
     const uint8_t* __restrict__ pixel_mask, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_dallmap, float* __restrict__ dgeom,
-    const uint32_t* __restrict__ tile_order, const uint8_t* __restrict__ stable) {
+    const uint32_t* __restrict__ tile_order, const uint8_t* __restrict__ stable,
+    const uint32_t* __restrict__ gate = nullptr, uint32_t gate_want = 0u) {
     __shared__ float4 rec[kBatchBwd * (kRec4 - 1)];
     __shared__ uint32_t ids[kBatchBwd];
     __shared__ unsigned long long hit[16];
     __shared__ uint32_t wmax[4];
+    // (gate: a device word decides whether this launch or its sibling of the other kLean does
+    // the work, see vings_surfel_blend_backward_auto)
+    if (gate && ((*gate != 0u) != (gate_want != 0u))) return;
     const int tile = tile_order ? (int)tile_order[blockIdx.x] : xcd_contiguous(blockIdx.x, gridDim.x);
     if ((unsigned)tile >= gridDim.x) return;   // a caller's order array with a stray entry
     const int tx = tile % gx, ty = tile / gx;
@@ -655,6 +659,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
     }
 }
 
+// flag |= 1 if any of the n floats is not +0 / -0 (NaN counts as non-zero)
+__global__ __launch_bounds__(256) void plane_nonzero_kernel(const float* __restrict__ p, size_t n,
+                                                            uint32_t* __restrict__ flag) {
+    bool any = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        any |= !(p[i] == 0.f);
+    if (__ballot(any) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
 }  // namespace vings
 
 using namespace vings;
@@ -831,4 +844,31 @@ extern "C" int vings_surfel_blend_backward_accumulate_stable(
     return blend_backward_impl(false, lean != 0, N, H, W, ranges, vals_sorted, geom, bg, pixel_mask,
                                final_T, n_contrib, dL_dcolor, dL_dallmap, dgeom, stream, tile_order,
                                stable_mask);
+}
+
+extern "C" int vings_surfel_blend_backward_auto(
+    int N, int H, int W, const uint32_t* ranges, const uint32_t* vals_sorted, const float* geom,
+    const float* bg, const uint8_t* pixel_mask, const float* final_T, const uint32_t* n_contrib,
+    const float* dL_dcolor, const float* dL_dallmap, float* dgeom, const uint32_t* tile_order,
+    uint32_t* flag_word, void* stream) {
+    VINGS_REQUIRE(N >= 0 && H > 0 && W > 0, "sizes");
+    if (N == 0) return VINGS_OK;
+    VINGS_REQUIRE(ranges && bg && final_T && n_contrib && dL_dcolor && dL_dallmap && dgeom && flag_word,
+                  "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t HW = (size_t)H * W;
+    VINGS_CHECK_HIP(hipMemsetAsync(flag_word, 0, sizeof(uint32_t), s));
+    ProfScope prof(PROF_BLEND_BWD, s);
+    plane_nonzero_kernel<<<cdiv((int64_t)HW, 256 * 8), 256, 0, s>>>(dL_dallmap + 5 * HW, HW, flag_word);
+    VINGS_LAUNCH_CHECK();
+    const int gx = (W + 15) / 16, gy = (H + 15) / 16;
+    blend_bwd_kernel<true><<<gx * gy, 256, 0, s>>>(H, W, gx, ranges, vals_sorted, geom, bg, pixel_mask,
+                                                   final_T, n_contrib, dL_dcolor, dL_dallmap, dgeom,
+                                                   tile_order, nullptr, flag_word, 0u);
+    VINGS_LAUNCH_CHECK();
+    blend_bwd_kernel<false><<<gx * gy, 256, 0, s>>>(H, W, gx, ranges, vals_sorted, geom, bg, pixel_mask,
+                                                    final_T, n_contrib, dL_dcolor, dL_dallmap, dgeom,
+                                                    tile_order, nullptr, flag_word, 1u);
+    VINGS_LAUNCH_CHECK();
+    return VINGS_OK;
 }

@@ -278,6 +278,10 @@ class SurfelMapper:
         (`mapping_loss_hip`); `torch_loss=True` builds the PyTorch graph of `mapping_loss`
         instead (the formulation the fixtures pin, kept as the cross-check).  `Rw2c_host` is
         the CPU copy of w2c[:3,:3]; passing it avoids a device->host read per view."""
+        for k in self.NAMES:
+            # (a fused view step leaves its own gradient buffers bound to .grad; autograd would
+            # add this view's gradients to whatever they hold)
+            self.params[k].grad = None
         scores = torch.zeros((self.n, 2), device=self.device, requires_grad=True)
         if torch_loss:
             pred = self.render(w2c, intr, scores=scores)
@@ -288,7 +292,8 @@ class SurfelMapper:
         rgb, radii, allmap = render_raw(self.params, w2c, intr, scores=scores)
         if Rw2c_host is None:
             Rw2c_host = w2c[:3, :3].cpu()
-        loss, loss_vec = mapping_loss_fused(rgb, allmap, gt, Rw2c_host, intr, self.loss_weights)
+        loss, loss_vec = mapping_loss_fused(rgb, allmap, gt, Rw2c_host, intr, self.loss_weights,
+                                            cache=True)
         loss.backward()
         self.last_loss = loss_vec[0]
         self.last_loss_terms = loss_vec
@@ -324,7 +329,9 @@ class SurfelMapper:
             self.globalkf_id = torch.where(replace, torch.full_like(self.globalkf_id, kf_id),
                                            self.globalkf_id)
         self.optimizer.step(vis, self.n)
-        self.optimizer.zero_grad(set_to_none=False)
+        # (gaussian_base.py:403 calls zero_grad() with torch's default, which drops the gradient
+        # tensors: the next backward assigns fresh ones instead of filling and adding)
+        self.optimizer.zero_grad()
         self._last_radii = radii
 
     # ------------------------------------------------------------------ multi-GPU records
@@ -385,9 +392,10 @@ class SurfelMapper:
             e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)
             fb = {"opac": e(n, 1), "scales": e(n, 2), "rot": e(n, 4), "vis": e(n, dt=torch.uint8),
                   "grads": {k: torch.zeros_like(self.params[k]) for k in self.NAMES}}
-            for k in self.NAMES:
-                self.params[k].grad = fb["grads"][k]   # the optimiser reads .grad
             self._fb = fb
+        for k in self.NAMES:
+            if self.params[k].grad is not self._fb["grads"][k]:
+                self.params[k].grad = self._fb["grads"][k]   # the optimiser reads .grad
         return self._fb
 
     def fused_view(self, settings, intr, gt, Rw2c_host, kf_id=0, reducer=None, lean=None):

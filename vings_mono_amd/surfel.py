@@ -372,6 +372,16 @@ def blend_backward(st, aux, g_color, g_allmap, dgeom=None, lean=False, stable=No
                   ptr(st.final_T), ptr(st.n_contrib), ptr(g_color), ptr(g_allmap), ptr(dgeom),
                   stream_ptr(dev)), "vings_surfel_blend_backward_accumulate")
         return dgeom
+    if aux[4] is None:
+        # no flow on the splats: the lean pass is exact whenever the incoming median-depth plane
+        # is all zeros, which is decided on the device (vings_surfel_blend_backward_auto)
+        dgeom = torch.zeros((max(N, 1), GRAD_STRIDE), dtype=torch.float32, device=dev)
+        flag = torch.empty(1, dtype=torch.int32, device=dev)
+        check(L.vings_surfel_blend_backward_auto(
+            N, H, W, ptr(st.ranges), ptr(st.vals), ptr(st.geom), ptr(bg), ptr(mask), ptr(st.final_T),
+            ptr(st.n_contrib), ptr(g_color), ptr(g_allmap), ptr(dgeom), ptr(st.tile_order), ptr(flag),
+            stream_ptr(dev)), "vings_surfel_blend_backward_auto")
+        return dgeom
     if st.tile_order is not None:
         # (the full pass in the forward pass's tile order; the ordered entry adds into its rows)
         dgeom = torch.zeros((max(N, 1), GRAD_STRIDE), dtype=torch.float32, device=dev)

@@ -35,6 +35,34 @@ def projection_matrix(fov_x, fov_y, znear=ZNEAR, zfar=ZFAR):
     return P
 
 
+_PROJ_T = {}
+
+
+def _projection_t(fov_x, fov_y, device):
+    """Transposed projection matrix on `device`, built once per (field of view, device): a
+    keyframe window renders with one intrinsic, and a pageable host-to-device copy per render
+    makes the host wait for everything queued on the stream before it."""
+    key = (float(fov_x), float(fov_y), str(device))
+    if key not in _PROJ_T:
+        if len(_PROJ_T) > 64:
+            _PROJ_T.clear()
+        _PROJ_T[key] = projection_matrix(fov_x, fov_y).T.contiguous().to(device)
+    return _PROJ_T[key]
+
+
+def _camera_center(w2c):
+    """inverse(w2c.T)[3, :3] (cameras.py:62-64) = -A^-1 t for w2c = [A t; 0 1], with the 3x3
+    inverse written out through cross products.  On the GPU `torch.linalg.inv` makes the host
+    wait for the whole stream (its LU reports a status word), once per render; these are a
+    handful of asynchronous elementwise launches."""
+    A, t = w2c[:3, :3], w2c[:3, 3]
+    c0, c1, c2 = A[:, 0], A[:, 1], A[:, 2]
+    r0, r1, r2 = torch.linalg.cross(c1, c2), torch.linalg.cross(c2, c0), torch.linalg.cross(c0, c1)
+    det = (c0 * r0).sum()
+    inv = torch.stack((r0, r1, r2)) / det
+    return (-(inv @ t)).contiguous()
+
+
 class Camera:
     """Matrices in the layout the rasteriser settings expect."""
 
@@ -45,9 +73,9 @@ class Camera:
         fov_y = focal_to_fov(intrinsic["fu"], self.height)
         fov_x = focal_to_fov(intrinsic["fv"], self.width)
         self.world_view_transform = w2c.T.contiguous()
-        self.projection_matrix = projection_matrix(fov_x, fov_y).T.contiguous().to(w2c.device)
+        self.projection_matrix = _projection_t(fov_x, fov_y, w2c.device)
         self.full_proj_transform = (self.world_view_transform @ self.projection_matrix).contiguous()
-        self.camera_center = torch.linalg.inv(self.world_view_transform)[3, :3].contiguous()
+        self.camera_center = _camera_center(w2c)
         self.tanfovx = math.tan(fov_x * 0.5)
         self.tanfovy = math.tan(fov_y * 0.5)
 
