@@ -6,9 +6,13 @@ from vings_mono_amd import synth
 
 
 def scene(n, W, H, seed=synth.SEED_BASE, view_k=0, n_views=1, scale_mul=1.0, z_range=(1.5, 60.0),
-          with_flow=False, bg=(0.0, 0.0, 0.0)):
-    """Activated splats + camera matrices as float32 numpy arrays."""
-    raw = synth.make_splats(n, W, H, n_views=n_views, seed=seed, z_range=z_range)
+          with_flow=False, bg=(0.0, 0.0, 0.0), kind="frustum"):
+    """Activated splats + camera matrices as float32 numpy arrays.  kind = "surfaces": opaque
+    splats on a ground plane, walls and facades (synth.make_surface_splats)."""
+    if kind == "surfaces":
+        raw = synth.make_surface_splats(n, W, H, n_views=n_views, seed=seed)
+    else:
+        raw = synth.make_splats(n, W, H, n_views=n_views, seed=seed, z_range=z_range)
     act = synth.activate(raw)
     c2w = synth.window_poses(max(n_views, view_k + 1))[view_k]
     w2c = torch.linalg.inv(c2w)

@@ -16,10 +16,12 @@ pytestmark = pytest.mark.gpu
 N, W, H = 1_000_000, 1920, 1080
 
 
-@pytest.fixture(scope="module")
-def full_scene():
+@pytest.fixture(scope="module", params=["frustum", "surfaces"])
+def full_scene(request):
+    """The bench's own scene (splats spread through the frustum) and the street of opaque
+    surfaces (synth.make_surface_splats), both at 1.0 M splats / 1080p."""
     dev = torch.device("cuda:0")
-    raw = synth.make_splats(N, W, H, n_views=8)
+    raw = (synth.make_surface_splats if request.param == "surfaces" else synth.make_splats)(N, W, H, n_views=8)
     act = {k: v.to(dev).contiguous() for k, v in synth.activate(raw).items()}
     c2w = synth.window_poses(8)[3]
     cam = synth.Camera(torch.linalg.inv(c2w).to(dev), synth.intrinsic_for(W, H))
@@ -72,6 +74,25 @@ def test_alpha_transmittance_and_ranges(full_scene):
     per_px = L.repeat_interleave(16, 0).repeat_interleave(16, 1)[:H, :W]
     assert bool((last <= per_px).all()) and bool((st.n_contrib[1] <= last).all())
     assert gy * gx == st.ranges.shape[0]
+
+
+def test_surfaces_scene_is_uneven_and_opaque(full_scene, request):
+    """What the second scene is there for: tile lists that differ by more than an order of
+    magnitude, some beyond the 2048 entries one LDS sort holds, and walks that end early on an
+    opaque surface."""
+    if request.node.callspec.params.get("full_scene") != "surfaces":
+        pytest.skip("a statement about the surfaces scene")
+    act, settings, st, aux = full_scene
+    L = (st.ranges[:, 1] - st.ranges[:, 0]).to(torch.float32)
+    filled = L[L > 0]
+    q = torch.quantile(filled, torch.tensor([0.05, 0.95], device=filled.device))
+    assert float(q[1]) >= 10.0 * float(q[0]), q
+    assert float(L.max()) > 2048
+    per_px = L.view((H + 15) // 16, (W + 15) // 16).repeat_interleave(16, 0).repeat_interleave(16, 1)[:H, :W]
+    covered = per_px > 0
+    walked = st.n_contrib[0].to(torch.float32)[covered].sum() / per_px[covered].sum()
+    assert float(walked) < 0.6, walked                 # most of a list lies behind the first surface
+    assert float(st.allmap[1][covered].mean()) > 0.8   # and the surface is opaque
 
 
 def test_blend_weight_is_conserved_into_scores(full_scene):

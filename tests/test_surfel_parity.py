@@ -97,6 +97,9 @@ CASES = [
     dict(n=30000, W=96, H=64, scale_mul=6.0),          # tile lists beyond one LDS sort (merge path)
     dict(n=200000, W=1920, H=1080),                    # BASELINE config 2
     dict(n=1000000, W=1920, H=1080, n_views=8, view_k=3),   # one view of BASELINE config 3
+    # opaque surfaces: lists from ~200 to ~10 000 entries (merge path), walks that end on the
+    # first surface (a quarter of the list on average)
+    dict(n=60000, W=256, H=144, kind="surfaces"),
 ]
 
 
@@ -205,6 +208,7 @@ BWD_CASES = [
     dict(n=3000, W=200, H=120, scale_mul=0.05),
     dict(n=200000, W=1920, H=1080),                    # BASELINE config 2
     dict(n=1000000, W=1920, H=1080, n_views=8, view_k=3),   # one view of BASELINE config 3
+    dict(n=60000, W=256, H=144, kind="surfaces"),      # opaque surfaces, early exits, long lists
 ]
 
 
