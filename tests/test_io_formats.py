@@ -41,6 +41,22 @@ def test_ply_layout_and_round_trip(tmp_path, mode, nscale):
     np.testing.assert_allclose(back["_rgb"], raw["_rgb"].numpy(), atol=1e-6)
 
 
+@pytest.mark.parametrize("mode", ["2dgs", "3dgs", "sky"])
+def test_ply_bytes_equal_the_layout_oracle(tmp_path, mode):
+    """save_ply against oracle/io_oracle.py, which packs the same file value by value with
+    `struct` from the reference's source: byte for byte."""
+    from oracle import io_oracle
+    raw = synth.make_splats(193, 64, 48, seed=11)
+    raw["_rgb"][:7] = torch.tensor([0.0, 1.0, 0.5, 0.1, 0.2, 0.3, 0.7])[:, None]   # round values too
+    path = tmp_path / f"o_{mode}.ply"
+    io_formats.save_ply(raw, str(path), mode)
+    want = io_oracle.ply_bytes(*(raw[k].tolist() for k in ("_xyz", "_rgb", "_opacity", "_scaling", "_rotation")),
+                               save_mode=mode)
+    assert path.read_bytes() == want
+    assert io_formats.ply_attributes(mode) == io_oracle.ply_attributes(mode)
+    assert tuple(sorted(io_formats.NAMES + tuple(io_formats.RECORDS))) == tuple(sorted(io_oracle.CKPT_KEYS))
+
+
 def test_ply_reader_rejects_other_layouts(tmp_path):
     p = tmp_path / "ascii.ply"
     p.write_text("ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nend_header\n0\n")

@@ -42,7 +42,10 @@ def save_ply(params, path, save_mode="2dgs"):
     names = ply_attributes(save_mode)
     if save_mode != "2dgs":
         scale = np.concatenate((scale, -10.0 * np.ones((n, 1), np.float32)), axis=1)
-    table = np.concatenate((xyz, np.zeros((n, 3), np.float32), (rgb - 0.5) / C0,
+    # (vis_utils.py:216 evaluates RGB2SH on a float32 CUDA tensor; there torch divides by a
+    # Python scalar by multiplying with the float32 reciprocal of the scalar)
+    sh = (rgb - np.float32(0.5)) * (np.float32(1.0) / np.float32(C0))
+    table = np.concatenate((xyz, np.zeros((n, 3), np.float32), sh,
                             np.zeros((n, 45), np.float32), opac.reshape(n, 1), scale, rot),
                            axis=1).astype("<f4")
     assert table.shape[1] == len(names)
