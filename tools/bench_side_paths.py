@@ -167,20 +167,26 @@ def main():
     # ---- on-the-fly correlation (no all-pairs volume) on the 1080p/8 grid ----------------------
     E_, h1, w1, C = 48, H // 8, W // 8, 128
     f1 = torch.randn(E_, h1, w1, C, device=dev)
-    total_f, total_b = 0.0, 0.0
+    # two target fields, named apart: a tracker's flow is smooth (neighbouring pixels look at
+    # neighbouring targets: the kernel's LDS-tiled path), targets scattered by 3 px per pixel
+    # are the worst case (level 0 falls back to global reads)
+    total = {"smooth_field_0.5px_jitter": 0.0, "scattered_field_3px_jitter": 0.0}
+    total_b = 0.0
     for lvl in range(4):
         h2, w2 = h1 >> lvl, w1 >> lvl
         f2 = torch.randn(E_, h2, w2, C, device=dev)
         xy = torch.stack(torch.meshgrid(torch.arange(w1, device=dev, dtype=torch.float32),
                                         torch.arange(h1, device=dev, dtype=torch.float32),
                                         indexing="xy"), -1)[None, None].repeat(E_, 1, 1, 1, 1)
-        c = ((xy + torch.randn_like(xy) * 3) / 2 ** lvl).contiguous()
-        total_f += timed(lambda: dba_mod.altcorr_forward(f1, f2, c, 3), a.reps)
+        for name, jitter in (("smooth_field_0.5px_jitter", 0.5), ("scattered_field_3px_jitter", 3.0)):
+            c = ((xy + 2.5 + torch.randn_like(xy) * jitter) / 2 ** lvl).contiguous()
+            total[name] += timed(lambda: dba_mod.altcorr_forward(f1, f2, c, 3), a.reps)
         g = torch.randn(E_, 1, 49, h1, w1, device=dev)
         total_b += timed(lambda: dba_mod.altcorr_backward(f1, f2, c, g, 3), a.reps)
         del f2
-    res["altcorr_forward_4_levels"] = entry(total_f, edges=E_, grid=[h1, w1], channels=C, radius=3,
-                                            flops=2 * 4 * E_ * h1 * w1 * 64 * C)
+    for name, t in total.items():
+        res["altcorr_forward_4_levels_" + name] = entry(t, edges=E_, grid=[h1, w1], channels=C, radius=3,
+                                                        flops=2 * 4 * E_ * h1 * w1 * 64 * C)
     res["altcorr_backward_4_levels"] = entry(total_b, edges=E_, grid=[h1, w1], channels=C, radius=3)
     del f1
 

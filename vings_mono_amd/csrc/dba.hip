@@ -251,6 +251,56 @@ __global__ __launch_bounds__(256) void dba_index_kernel(const int64_t* __restric
     }
     for (int e = tid; e < E; e += 256) W.kk[e] = pos[W.ip[e]];
     __syncthreads();
+    if (E <= kLdsEdges) {
+        // The lists in parallel.  An edge's place inside its source frame's lists is its rank
+        // among the earlier edges of that frame (all edges / those whose target pose is free),
+        // counted by its own lane over the endpoints in LDS; the list starts are prefix sums
+        // of the per-frame counts.  Same lists as the serial loop below, entry for entry.
+        __shared__ int cnt_free[kMaxFrames];
+        int* cnt_all = flag;                         // (the frame flags have been consumed)
+        for (int k = tid; k < M; k += 256) { cnt_all[k] = 0; cnt_free[k] = 0; }
+        __syncthreads();
+        for (int e = tid; e < E; e += 256) {
+            const int k = pos[sip[e]];
+            atomicAdd(&cnt_all[k], 1);
+            if (sjp[e] >= t0 && sjp[e] < t1) atomicAdd(&cnt_free[k], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int ce = 0, cn = 0;
+            for (int k = 0; k < M; ++k) {
+                W.kstart[k] = ce;
+                W.ent_start[k] = cn;
+                const int f = W.kx[k];
+                ce += cnt_all[k];
+                cn += cnt_free[k] + ((f >= t0 && f < t1) ? 1 : 0);
+            }
+            W.kstart[M] = ce;
+            W.ent_start[M] = cn;
+        }
+        __syncthreads();
+        for (int k = tid; k < M; k += 256) {
+            const int f = W.kx[k];
+            if (f >= t0 && f < t1) { const int n = W.ent_start[k]; W.ent_row[n] = f - t0; W.ent_pose[n] = f - t0; }
+        }
+        for (int e = tid; e < E; e += 256) {
+            const int src = sip[e], j = sjp[e];
+            int r_all = 0, r_free = 0;
+            for (int q = 0; q < e; ++q) {
+                if (sip[q] != src) continue;
+                ++r_all;
+                r_free += (sjp[q] >= t0 && sjp[q] < t1) ? 1 : 0;
+            }
+            const int k = pos[src];
+            W.kedges[W.kstart[k] + r_all] = e;
+            if (j >= t0 && j < t1) {
+                const int n = W.ent_start[k] + ((src >= t0 && src < t1) ? 1 : 0) + r_free;
+                W.ent_row[n] = (t1 - t0) + e;
+                W.ent_pose[n] = j - t0;
+            }
+        }
+        return;
+    }
     // per depth variable: edge list (in edge order) and entry list
     if (tid == 0) {
         int ce = 0, cn = 0;
@@ -653,12 +703,15 @@ __device__ __forceinline__ double lane_bcast(double v, int l) {
 __global__ __launch_bounds__(256) void dba_solve_wave_kernel(int n, double lm, double ep,
                                                             int use_schur, DbaWs W) {
     extern __shared__ double lds[];
-    __shared__ double col[64];
+    __shared__ double panel[64][8];     // L[i][j0 .. j0+5] of the current block column
+    __shared__ double rdiag[64];        // 1 / L[i][i]
+    __shared__ int fail_s;
     const int ld = n | 1;
     double* A = lds;
     const int i = threadIdx.x;
+    if (i == 0) fail_s = 0;
     // four waves fetch the matrix (one wave alone would queue 36 dependent-latency rounds of
-    // global loads); from the barrier on only the first wave works, the others have ended
+    // global loads)
     for (int idx = i; idx < n * n; idx += 256) {
         const int r = idx / n, c = idx - r * n;
         double a = W.H[idx];
@@ -667,26 +720,77 @@ __global__ __launch_bounds__(256) void dba_solve_wave_kernel(int n, double lm, d
         A[r * ld + c] = a;
     }
     __syncthreads();
-    if (i >= 64) return;
-    bool fail = false;
-    double rd = 0.0;                                   // 1 / L[i][i], kept by lane i
-    for (int j = 0; j < n; ++j) {
-        const double djj = A[j * ld + j];
-        if (!(djj > 0.0)) { fail = true; break; }      // uniform over the wave
-        const double inv = 1.0 / sqrt(djj);
-        if (i == j) rd = inv;
-        double lij = 0.0;
-        if (i >= j && i < n) { lij = A[i * ld + j] * inv; A[i * ld + j] = lij; col[i] = lij; }
+    // Right-looking factorisation in block columns of six (n = 6 P: one pose per block), two
+    // barriers per BLOCK instead of two per column.  Step 1: lane i (row i >= j0) reads the
+    // 6 x 6 diagonal block as LDS broadcasts, factors it in registers -- every lane the same
+    // 56 flops, no exchange -- and solves its own row of the panel against it.  Step 2: all
+    // 256 lanes subtract panel x panel^T from the trailing matrix, one element per lane and
+    // round, each element touched once per block instead of once per column.
+    for (int j0 = 0; j0 < n; j0 += 6) {
+        if (i >= j0 && i < n) {
+            double L[6][6], inv[6];
+            bool bad = false;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double d = A[(j0 + c) * ld + j0 + c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) d -= L[c][k] * L[c][k];
+                bad |= !(d > 0.0);
+                inv[c] = 1.0 / sqrt(d);
+                L[c][c] = d * inv[c];
+#pragma unroll
+                for (int r = c + 1; r < 6; ++r) {
+                    double v = A[(j0 + r) * ld + j0 + c];
+#pragma unroll
+                    for (int k = 0; k < c; ++k) v -= L[r][k] * L[c][k];
+                    L[r][c] = v * inv[c];
+                }
+            }
+            if (bad) fail_s = 1;
+            double x[6];
+            if (i >= j0 + 6) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    double v = A[i * ld + j0 + c];
+#pragma unroll
+                    for (int k = 0; k < c; ++k) v -= x[k] * L[c][k];
+                    x[c] = v * inv[c];
+                }
+            } else {
+                const int r = i - j0;
+                double iv = 0.0;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) iv = (q == r) ? inv[q] : iv;
+                rdiag[i] = iv;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int q = c; q < 6; ++q) v = (q == r) ? L[q][c] : v;
+                    x[c] = v;                  // zero right of the diagonal
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) { A[i * ld + j0 + c] = x[c]; panel[i][c] = x[c]; }
+        }
         __syncthreads();
-        // the column sits in an array of its own: the compiler can then see that the row
-        // updates do not feed the column reads and overlap the LDS round trips
-        if (i > j && i < n) {
-            double* __restrict__ row = A + i * ld;
-#pragma unroll 8
-            for (int b = j + 1; b <= i; ++b) row[b] -= lij * col[b];
+        if (fail_s) break;
+        const int m0 = j0 + 6, m = n - m0;
+        for (int idx = i; idx < m * m; idx += 256) {
+            const int r = idx / m, c = idx - r * m;
+            if (c > r) continue;
+            const double* pr = panel[m0 + r];
+            const double* pc = panel[m0 + c];
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc += pr[k] * pc[k];
+            A[(m0 + r) * ld + m0 + c] -= acc;
         }
         __syncthreads();
     }
+    const bool fail = fail_s != 0;
+    if (i >= 64) return;
+    const double rd = i < n ? rdiag[i] : 0.0;          // 1 / L[i][i], kept by lane i
     if (fail) {  // chol.py:9-17: a failed factorisation yields a zero update
         if (i < n) W.dx[i] = 0.0;
         if (i == 0) W.status[1] = 1;
