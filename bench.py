@@ -436,7 +436,10 @@ def main():
                 "note": "achieved / avg_kernel_ms are measured in this run (HIP events on the "
                         "launch stream); traffic is NOT: it is the FETCH_SIZE / WRITE_SIZE "
                         "figure of the committed rocprofv3 PMC passes of this same workload "
-                        "(profiles/, null for any other workload).  The kernel is bound by "
+                        "(profiles/, null for any other workload), as 2 x FETCH_SIZE + WRITE_SIZE: the doubling "
+                        "is the guide's correction for wide streaming reads, an upper bound for this "
+                        "kernel's 16-byte gathers (the un-doubled sum is in the same profile record).  "
+                        "The kernel is bound by "
                         "vector-instruction issue, not by HBM (profiles/*/blend_sq_counters.txt: "
                         "7.46e8 VALU wave-instructions per launch on 1024 SIMDs, 3.3 cycles each "
                         "at 2.4 GHz = the measured millisecond); "
