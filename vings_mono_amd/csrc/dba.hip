@@ -8,7 +8,9 @@
 //                walks all edges leaving that frame, so the depth block C, the
 //                depth residual w and the pose/depth coupling of the source
 //                pose are reduced in registers (no per-edge intermediates, no
-//                scatter pass); 6x6 pose blocks are wave-reduced and added to
+//                scatter pass); the 6x6 pose blocks and right-hand sides of an
+//                edge are J^T W J products on the matrix cores
+//                (v_mfma_f64_16x16x4_f64 over the wave's 64 pixels), added to
 //                a float64 accumulator
 //   schur      : S = E Q E^T and u = E Q w as an MFMA block GEMM
 //                (v_mfma_f64_16x16x4_f64) over the pixel axis, block sparsity
@@ -27,6 +29,8 @@
 // /root/reference/scripts/frontend/depth_video.py:380-381,475-481,550-568,649-650;
 // the mathematics follow /root/reference/scripts/frontend/geom/ba.py:29-104,
 // chol.py:32-73 and projective_ops.py:18-125.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace vings {
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(256) void dba_index_kernel(const int64_t* __restric
 // ---------------------------------------------------------------------------
 // linearize
 // ---------------------------------------------------------------------------
-constexpr int kNH = 21 + 36 + 21 + 6 + 6;  // Hii(upper) Hij Hjj(upper) vi vj
+using f64x4 = __attribute__((ext_vector_type(4))) double;
 
 __device__ __forceinline__ constexpr int tri(int a, int b) {  // (a<=b) in a 6x6 upper triangle
     return a * 6 - a * (a - 1) / 2 + (b - a);
@@ -336,7 +340,10 @@ __global__ __launch_bounds__(256) void dba_linearize_kernel(
     const float* __restrict__ target, const float* __restrict__ weight,
     const float* __restrict__ eta, int ht, int wd, int E, int M, int t0, int t1, int motion_only,
     DbaWs W) {
-    __shared__ double red[4][kNH];
+    constexpr int kTileLd = 17;
+    __shared__ double tile[4][64 * kTileLd];   // per wave: its pixels' 13-vectors (+ 3 zero rows)
+    __shared__ double wts[4][64];
+    __shared__ double Cs[2][4][13 * 13];       // the waves' products, double-buffered over the edges
     const int k = blockIdx.y;
     const int HW = ht * wd;
     const int P = t1 - t0;
@@ -353,12 +360,60 @@ __global__ __launch_bounds__(256) void dba_linearize_kernel(
     const double X0[3] = {((double)pu - cx) / fx, ((double)pvv - cy) / fy, 1.0};
     const bool i_free = i >= t0 && i < t1;
     double Cacc = 0., wacc = 0., Ei[6] = {0, 0, 0, 0, 0, 0};
+    // the entry of the 13 x 13 product this lane adds up over the four waves (lanes < 169)
+    const int ca = threadIdx.x / 13, cb = threadIdx.x - ca * 13;
+    const bool own_block = threadIdx.x < 13 * 13 && ca < 6 && (cb < 6 || cb == 12);
+    const int n6 = 6 * P, ib = (i - t0) * 6;
+    double carry = 0.0;
+    int buf = 0;
+    // rows 13..15 of the MFMA operands stay zero for the whole kernel
+    tile[wv][lane * kTileLd + 13] = 0.; tile[wv][lane * kTileLd + 14] = 0.;
+    tile[wv][lane * kTileLd + 15] = 0.; tile[wv][lane * kTileLd + 16] = 0.;
 
-    for (int idx = e0; idx < e1; ++idx) {
-        const int e = W.kedges[idx];
+    // The edges leaving this frame, their target frames and relative poses, once per workgroup:
+    // read per edge inside the loop they are three dependent memory round trips (edge list ->
+    // target frame -> its pose) in front of every edge's arithmetic.
+    constexpr int kEdgeCache = 32;
+    __shared__ int s_e[kEdgeCache], s_j[kEdgeCache];
+    __shared__ double s_G[kEdgeCache][8];
+    if ((int)threadIdx.x < min(e1 - e0, kEdgeCache)) {
+        const int e = W.kedges[e0 + threadIdx.x];
         const int j = W.jp[e];
-        const bool j_free = j >= t0 && j < t1;
         const Se3d G = relative_pose(poses, i, j);
+        s_e[threadIdx.x] = e; s_j[threadIdx.x] = j;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s_G[threadIdx.x][c] = G.t[c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s_G[threadIdx.x][3 + c] = G.q[c];
+    }
+    __syncthreads();
+    // this pixel's flow target and weights of an edge; the next edge's are fetched while the
+    // current edge is worked on
+    auto fetch = [&](int idx, float (&tw)[4]) {
+        tw[0] = tw[1] = tw[2] = tw[3] = 0.f;
+        if (idx >= e1 || !act) return;
+        const int e = idx - e0 < kEdgeCache ? s_e[idx - e0] : W.kedges[idx];
+        const size_t o = ((size_t)e * 2) * HW + p;
+        tw[0] = target[o]; tw[1] = target[o + HW]; tw[2] = weight[o]; tw[3] = weight[o + HW];
+    };
+    float tw_next[4];
+    fetch(e0, tw_next);
+    for (int idx = e0; idx < e1; ++idx) {
+        const bool cached = idx - e0 < kEdgeCache;
+        const int e = cached ? s_e[idx - e0] : W.kedges[idx];
+        const int j = cached ? s_j[idx - e0] : W.jp[e];
+        const bool j_free = j >= t0 && j < t1;
+        Se3d G;
+        if (cached) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) G.t[c] = s_G[idx - e0][c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) G.q[c] = s_G[idx - e0][3 + c];
+        } else {
+            G = relative_pose(poses, i, j);
+        }
+        float tw[4] = {tw_next[0], tw_next[1], tw_next[2], tw_next[3]};
+        fetch(idx + 1, tw_next);
         double X1[3];
         qrot(G.q, X0, X1);
         X1[0] += G.t[0] * d; X1[1] += G.t[1] * d; X1[2] += G.t[2] * d;
@@ -368,11 +423,10 @@ __global__ __launch_bounds__(256) void dba_linearize_kernel(
         const double xn = X1[0] * dz, yn = X1[1] * dz;
         double r[2] = {0, 0}, wt[2] = {0, 0};
         if (valid) {
-            const size_t o = ((size_t)e * 2) * HW + p;
-            r[0] = (double)target[o] - (fx * xn + cx);
-            r[1] = (double)target[o + HW] - (fy * yn + cy);
-            wt[0] = 0.001 * (double)weight[o];
-            wt[1] = 0.001 * (double)weight[o + HW];
+            r[0] = (double)tw[0] - (fx * xn + cx);
+            r[1] = (double)tw[1] - (fy * yn + cy);
+            wt[0] = 0.001 * (double)tw[2];
+            wt[1] = 0.001 * (double)tw[3];
         }
         // rows of d(coords)/d(xi_j), twist ordered (tau, phi)
         double Jj[2][6], Ji[2][6], Jz[2];
@@ -410,70 +464,68 @@ __global__ __launch_bounds__(256) void dba_linearize_kernel(
             }
         }
         if (!i_free && !j_free) continue;  // both poses fixed: nothing for the pose block
-        double hacc[kNH];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-#pragma unroll
-            for (int b = a; b < 6; ++b) {
-                hacc[tri(a, b)] = wt[0] * Ji[0][a] * Ji[0][b] + wt[1] * Ji[1][a] * Ji[1][b];
-                hacc[57 + tri(a, b)] = wt[0] * Jj[0][a] * Jj[0][b] + wt[1] * Jj[1][a] * Jj[1][b];
-            }
-#pragma unroll
-            for (int b = 0; b < 6; ++b)
-                hacc[21 + a * 6 + b] = wt[0] * Ji[0][a] * Jj[0][b] + wt[1] * Ji[1][a] * Jj[1][b];
-            hacc[78 + a] = wt[0] * Ji[0][a] * r[0] + wt[1] * Ji[1][a] * r[1];
-            hacc[84 + a] = wt[0] * Jj[0][a] * r[0] + wt[1] * Jj[1][a] * r[1];
-        }
-        // Transposing wave reduction of the 90 sums (padded to 92): a permlane32 swap + add
-        // sums two values over lanes l / l+32 and leaves one per half, a permlane16 swap + add
-        // does the same for rows; 23 registers then hold four values each (row r of register k
-        // = value 4k + {0,2,1,3}[r]) and a DPP row sum finishes them.
+        // J^T W J of this edge on the matrix cores.  Per residual row c the lane's pixel has the
+        // 13-vector a = (Ji[c][0..5], Jj[c][0..5], r[c]); the 13 x 13 matrix sum_pixels wt a a^T
+        // holds Hii, Hij, Hjj, vi and vj.  v_mfma_f64_16x16x4_f64 takes four pixels at a time:
+        // lane l supplies A[row l&15][pixel l>>4] and B = wt * the same element, so every lane
+        // reads ONE value per instruction from a per-wave LDS tile that the lanes filled with
+        // their own vectors (pixel-major rows of 17 doubles: the 16 rows of an operand are
+        // consecutive words, the four pixels of it 34 banks apart).  16 instructions per
+        // residual row replace 90 products and the 90-value wave reduction that followed them.
         {
-            double v46[46];
+            double* __restrict__ T = tile[wv];
+            f64x4 acc = {0., 0., 0., 0.};
 #pragma unroll
-            for (int q = 0; q < 45; ++q) v46[q] = swap_add_d2<true>(hacc[2 * q], hacc[2 * q + 1]);
-            v46[45] = 0.0;
-            const int row = lane >> 4;
-            const int comp0 = ((row & 1) << 1) | (row >> 1);
+            for (int c = 0; c < 2; ++c) {
+                double* mine = T + lane * kTileLd;
 #pragma unroll
-            for (int q = 0; q < 23; ++q) {
-                const double u = row_sum_d(swap_add_d2<false>(v46[2 * q], v46[2 * q + 1]));
-                const int dst = 4 * q + comp0;
-                if ((lane & 15) == 0 && dst < kNH) red[wv][dst] = u;
+                for (int m = 0; m < 6; ++m) { mine[m] = Ji[c][m]; mine[6 + m] = Jj[c][m]; }
+                mine[12] = r[c];
+                wts[wv][lane] = wt[c];
+                // same wave writes and reads: LDS operations of a wave complete in order
+                __builtin_amdgcn_wave_barrier();
+                const double* src = T + (lane >> 4) * kTileLd + (lane & 15);
+                const double* wsrc = wts[wv] + (lane >> 4);
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    const double a = src[4 * m * kTileLd];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a * wsrc[4 * m], acc, 0, 0, 0);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            // C[row (l>>4) + 4q][col l&15] of this wave's 64 pixels
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = (lane >> 4) + 4 * q, col = lane & 15;
+                if (row < 13 && col < 13) Cs[buf][wv][row * 13 + col] = acc[q];
             }
         }
-        __syncthreads();
-        const int n6 = 6 * P;
-        const int ib = (i - t0) * 6, jb = (j - t0) * 6;
-        for (int q = threadIdx.x; q < kNH; q += 256) {
-            const double s = red[0][q] + red[1][q] + red[2][q] + red[3][q];
-            if (s == 0.0) continue;
-            if (q < 21) {  // Hii upper
-                if (!i_free) continue;
-                int a = 0, rem = q;
-                while (rem >= 6 - a) { rem -= 6 - a; ++a; }
-                const int b = a + rem;
-                atomicAdd(&W.H[(size_t)(ib + a) * n6 + ib + b], s);
-                if (a != b) atomicAdd(&W.H[(size_t)(ib + b) * n6 + ib + a], s);
-            } else if (q < 57) {  // Hij and its transpose Hji
-                if (!(i_free && j_free)) continue;
-                const int a = (q - 21) / 6, b = (q - 21) % 6;
-                atomicAdd(&W.H[(size_t)(ib + a) * n6 + jb + b], s);
-                atomicAdd(&W.H[(size_t)(jb + b) * n6 + ib + a], s);
-            } else if (q < 78) {  // Hjj upper
-                if (!j_free) continue;
-                int a = 0, rem = q - 57;
-                while (rem >= 6 - a) { rem -= 6 - a; ++a; }
-                const int b = a + rem;
-                atomicAdd(&W.H[(size_t)(jb + a) * n6 + jb + b], s);
-                if (a != b) atomicAdd(&W.H[(size_t)(jb + b) * n6 + jb + a], s);
-            } else if (q < 84) {
-                if (i_free) atomicAdd(&W.v[ib + (q - 78)], s);
-            } else {
-                if (j_free) atomicAdd(&W.v[jb + (q - 84)], s);
+        // One barrier per edge, and one that waits for LDS only: __syncthreads also waits for
+        // every outstanding global store and atomic of the wave (the E rows, the adds into H),
+        // a memory round trip per edge.  The four waves' tiles are double-buffered, so one
+        // barrier per edge is enough.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (threadIdx.x < 13 * 13) {
+            const int o = ca * 13 + cb;
+            const double s = (Cs[buf][0][o] + Cs[buf][1][o]) + (Cs[buf][2][o] + Cs[buf][3][o]);
+            if (own_block) {
+                carry += s;                      // (i, i) block and v_i: the same for every edge
+            } else if (s != 0.0 && ca < 12) {
+                // rows / columns 0..5: pose i, 6..11: pose j, 12: the residual
+                const int jb = (j - t0) * 6;
+                const bool a_i = ca < 6, b_i = cb < 6;
+                if ((a_i ? i_free : j_free) && (cb == 12 || (b_i ? i_free : j_free))) {
+                    const int ra = a_i ? ib + ca : jb + ca - 6;
+                    if (cb == 12) atomicAdd(&W.v[ra], s);
+                    else atomicAdd(&W.H[(size_t)ra * n6 + (b_i ? ib + cb : jb + cb - 6)], s);
+                }
             }
         }
-        __syncthreads();
+        buf ^= 1;
+    }
+    if (own_block && i_free && carry != 0.0) {
+        if (cb == 12) atomicAdd(&W.v[ib + ca], carry);
+        else atomicAdd(&W.H[(size_t)(ib + ca) * n6 + ib + cb], carry);
     }
     if (motion_only || !act) return;
     if (i_free) {
@@ -493,121 +545,179 @@ __global__ __launch_bounds__(256) void dba_linearize_kernel(
 // Schur complement as an MFMA block GEMM.
 // For depth variable k the rows of Y are its entries' 6 coupling rows plus the
 // residual row w; G = (Y diag(Q)) Y^T is accumulated in 16x16 f64 MFMA tiles
-// over a slice of the pixel axis and scattered (float64 atomics) into S and u.
+// over the pixel axis and added into S and u.
 // Operand map of v_mfma_f64_16x16x4_f64: lane l holds A[l&15][l>>4] and
 // B[l>>4][l&15]; result reg r of lane l is C[(l>>4) + 4r][l&15].
 // ---------------------------------------------------------------------------
-using f64x4 = __attribute__((ext_vector_type(4))) double;
-constexpr int kSchurSlice = 64;
-// 64 rows + the Q row, 65 doubles each = 33 KB of LDS: four workgroups per CU
-constexpr size_t kSchurLds = (size_t)65 * (kSchurSlice + 1) * sizeof(double);
-// Pixels per workgroup: long spans amortise the scatter of the tiles into S, short ones give
-// a small grid (the reference's own 43x77) enough workgroups to fill the chip.
-static int schur_span(int HW, int M) {
-    int s = 2048;
-    while (s > kSchurSlice && (int64_t)cdiv(HW, s) * M < 512) s >>= 1;
-    return s;
+constexpr int kSchurWaves = 8;                 // per workgroup
+constexpr int kSchurThreads = 64 * kSchurWaves;
+
+// Pixels per wave (a multiple of 16) and workgroups per depth variable: about one workgroup
+// per CU (its eight waves are two per SIMD), fewer when that would leave a wave under two
+// 16-pixel steps -- every further workgroup costs one more round of atomics on S.
+struct SchurGrid { int pxw, gx; };
+static SchurGrid schur_grid(int HW, int M) {
+    static const int target = [] { const char* e = getenv("VINGS_SCHUR_WGS"); return e ? atoi(e) : 256; }();
+    int gx = target / (M > 0 ? M : 1);
+    gx = min(gx, HW / (32 * kSchurWaves));
+    if (gx < 1) gx = 1;
+    int pxw = (cdiv(HW, gx * kSchurWaves) + 15) & ~15;
+    if (pxw < 16) pxw = 16;
+    return SchurGrid{pxw, cdiv(HW, kSchurWaves * pxw)};
 }
 
-// A workgroup covers `span` pixels of depth variable k in chunks of `slice` (a power of two)
-// staged through LDS, keeps its tiles' accumulators in registers over the chunks and
-// scatters them once: the float64 atomics into S were half of the kernel's time when every
-// 128-pixel slice scattered its own tiles.
-__global__ __launch_bounds__(256) void dba_schur_kernel(int HW, int P, int slice, int span,
-                                                        DbaWs W) {
-    const int k = blockIdx.y;
-    if (W.status[2]) return;
-    const int n0 = W.ent_start[k], n1 = W.ent_start[k + 1];
-    const int nent = n1 - n0;
-    if (nent == 0) return;
-    const int nrows = 6 * nent + 1;
-    const int R16 = (nrows + 15) / 16;
+// G[ra][rc] of depth variable k (rows counted over its entries, the last one w) into S and u;
+// a tile above the diagonal also feeds its mirror image
+__device__ __forceinline__ void schur_add(const DbaWs& W, int n0, int nrows, int n6, int ra, int rc,
+                                          bool mirror, double val) {
+    if (ra >= nrows - 1 || rc >= nrows || val == 0.0) return;
+    const int ea = ra / 6, ca = ra - ea * 6;
+    const int ia = W.ent_pose[n0 + ea] * 6 + ca;
+    if (rc == nrows - 1) {
+        atomicAdd(&W.u[ia], val);
+    } else {
+        const int eb = rc / 6, cc = rc - eb * 6;
+        const int ibx = W.ent_pose[n0 + eb] * 6 + cc;
+        atomicAdd(&W.S[(size_t)ia * n6 + ibx], val);
+        if (mirror) atomicAdd(&W.S[(size_t)ibx * n6 + ia], val);
+    }
+}
+
+// Up to 64 rows per depth variable (R16 <= 4 panels of 16 rows, i.e. up to ten edges leaving a
+// frame), no LDS staging and no barrier in the main loop: a wave owns a run of `pxw` pixels and
+// ALL upper tiles over it.  Per 16 pixels ("step") lane (r, g) loads, for one row of every
+// panel, the two pixel pairs 2g, 2g+1 and 8+2g, 8+2g+1 (16 bytes each; the four g lanes of a row
+// cover 64 contiguous bytes per load, each element of E is read exactly once by exactly one
+// lane) plus the same pixels of Q, and issues R16 (R16 + 1) / 2 x 4 matrix instructions into as
+// many independent accumulators.  The registers of a step are reloaded with the step kDepth
+// later as soon as its matrix instructions have issued, so the loads fly while the next steps
+// run; the register budget (256) keeps two waves on a SIMD, which covers the rest of the
+// latency.  Padding rows of the last panel read the w row: they only reach tile entries that
+// are never added anywhere.  A run's ragged last step (the end of the image) goes through a
+// guarded copy of the step.
+// The eight waves of a workgroup add their tiles up in LDS (ds_add_f64) and the workgroup adds
+// the sums into S and u once: a few thousand float64 atomics per workgroup, all workgroups on
+// the same few hundred cache lines, which is why a workgroup is made as large as the
+// registers allow and the grid is kept near one workgroup per CU.
+typedef double f64x2u __attribute__((ext_vector_type(2), aligned(8)));
+
+template <int R16>
+__device__ __forceinline__ void schur_rows_body(int HW, int P, int pxw, int k, int n0, int nrows,
+                                                const DbaWs& W, double* __restrict__ red) {
+    constexpr int NT = R16 * (R16 + 1) / 2;
+    constexpr int kDepth = R16 <= 3 ? 3 : 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int k0 = blockIdx.x * span;
-    const int k1 = min(HW, k0 + span);
+    const int w0 = min(HW, (blockIdx.x * kSchurWaves + wv) * pxw);
+    const int w1 = min(HW, w0 + pxw);
+    const int nfull = (w1 - w0) >> 4;      // whole steps; a remainder only at the image's end
+    const double* Qk = W.Q + (size_t)k * HW + w0 + 2 * g;
+    const double* rq[R16];
+#pragma unroll
+    for (int b = 0; b < R16; ++b) {
+        const int rho = b * 16 + r;
+        const double* base = W.w + (size_t)k * HW;
+        if (rho < nrows - 1) {
+            const int ent = rho / 6, c = rho - ent * 6;
+            base = W.E + ((size_t)W.ent_row[n0 + ent] * 6 + c) * HW;
+        }
+        rq[b] = base + w0 + 2 * g;
+    }
+    for (int q = threadIdx.x; q < NT * 256; q += kSchurThreads) red[q] = 0.0;
+    f64x4 acc[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) acc[q] = f64x4{0., 0., 0., 0.};
+    f64x2u st[kDepth][R16][2], sq[kDepth][2];
+    // step t of this run into ring slot u; past the last whole step the last one is read again
+    // (never used), so that every load is unconditional and the compiler can count them
+    auto fetch = [&](int u, int t) {
+        const int off = 16 * min(t, nfull - 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            sq[u][h] = *(const f64x2u*)(Qk + off + 8 * h);
+#pragma unroll
+            for (int b = 0; b < R16; ++b) st[u][b][h] = *(const f64x2u*)(rq[b] + off + 8 * h);
+        }
+    };
+    auto products = [&](const f64x2u (&y)[R16][2], const f64x2u (&qv)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                double aq[R16];
+#pragma unroll
+                for (int b = 0; b < R16; ++b) aq[b] = y[b][h][e] * qv[h][e];
+                int q = 0;
+#pragma unroll
+                for (int rb = 0; rb < R16; ++rb)
+#pragma unroll
+                    for (int cb = rb; cb < R16; ++cb, ++q)
+                        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[rb], y[cb][h][e], acc[q], 0, 0, 0);
+            }
+    };
+    if (nfull > 0) {
+#pragma unroll
+        for (int u = 0; u < kDepth; ++u) fetch(u, u);
+        for (int t = 0; t < nfull; t += kDepth) {
+#pragma unroll
+            for (int u = 0; u < kDepth; ++u) {
+                if (t + u >= nfull) break;
+                products(st[u], sq[u]);
+                fetch(u, t + u + kDepth);
+            }
+        }
+    }
+    if (w0 + 16 * nfull < w1) {            // the ragged step
+        f64x2u y[R16][2], qv[2];
+        const int off = 16 * nfull;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int o = off + 8 * h + e;
+                const bool in = w0 + 2 * g + o < w1;
+                qv[h][e] = in ? Qk[o] : 0.0;
+#pragma unroll
+                for (int b = 0; b < R16; ++b) y[b][h][e] = in ? rq[b][o] : 0.0;
+            }
+        products(y, qv);
+    }
+    __syncthreads();                       // red[] cleared
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+            if (acc[q][reg] != 0.0) atomicAdd(&red[(q * 4 + reg) * 64 + lane], acc[q][reg]);
+    __syncthreads();
+    // entry idx of the partial tiles: tile idx >> 8, result register (idx >> 6) & 3, lane idx & 63
+    const int n6 = 6 * P;
+    for (int idx = threadIdx.x; idx < NT * 256; idx += kSchurThreads) {
+        const double val = red[idx];
+        int q = idx >> 8, rb = 0;
+        while (q >= R16 - rb) { q -= R16 - rb; ++rb; }
+        const int cb = rb + q, sl = idx & 63, sreg = (idx >> 6) & 3;
+        schur_add(W, n0, nrows, n6, rb * 16 + (sl >> 4) + 4 * sreg, cb * 16 + (sl & 15), rb != cb, val);
+    }
+}
+
+// More than 64 rows (over ten edges leaving one frame): a wave takes tiles in turn over the
+// workgroup's whole pixel span, panels straight from global memory, and adds them to S itself.
+__device__ __forceinline__ void schur_wide_body(int HW, int P, int pxw, int k, int n0, int nrows,
+                                                const DbaWs& W) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int R16 = (nrows + 15) / 16;
+    const int k0 = min(HW, (int)blockIdx.x * kSchurWaves * pxw);
+    const int k1 = min(HW, k0 + kSchurWaves * pxw);
     const double* Qk = W.Q + (size_t)k * HW;
     const int n6 = 6 * P;
-
     auto row_ptr = [&](int rho) -> const double* {
         if (rho >= nrows) return nullptr;
         if (rho == nrows - 1) return W.w + (size_t)k * HW;
         const int ent = rho / 6, c = rho - ent * 6;
         return W.E + ((size_t)W.ent_row[n0 + ent] * 6 + c) * HW;
     };
-    auto scatter = [&](int rb, int cb, const f64x4& acc) {
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int ra = rb * 16 + g + 4 * reg, rc = cb * 16 + r;
-            if (ra >= nrows - 1 || rc >= nrows) continue;
-            const double val = acc[reg];
-            if (val == 0.0) continue;
-            const int ea = ra / 6, ca = ra - ea * 6;
-            const int ia = W.ent_pose[n0 + ea] * 6 + ca;
-            if (rc == nrows - 1) {
-                atomicAdd(&W.u[ia], val);
-            } else {
-                const int eb = rc / 6, cc = rc - eb * 6;
-                const int ibx = W.ent_pose[n0 + eb] * 6 + cc;
-                atomicAdd(&W.S[(size_t)ia * n6 + ibx], val);
-                if (rb != cb) atomicAdd(&W.S[(size_t)ibx * n6 + ia], val);
-            }
-        }
-    };
-
-    extern __shared__ double ys[];
-    const int ld = slice + 1;          // odd: the 16 rows of a panel spread over the banks
-    const bool staged = R16 <= 4 && (size_t)(R16 * 16 + 1) * ld * sizeof(double) <= kSchurLds;
-    if (staged) {
-        // Every row's chunk is staged in LDS once: each of the R16 (R16+1)/2 tiles re-reads
-        // two 16-row panels, which from global memory is 3-4x the traffic of E.
-        double* qs = ys + (size_t)R16 * 16 * ld;
-        __shared__ const double* rows[64];
-        // row addresses first (each costs a dependent table lookup), then copies with
-        // nothing but independent loads in their loop
-        if ((int)threadIdx.x < R16 * 16) rows[threadIdx.x] = row_ptr(threadIdx.x);
-        const int sh = __builtin_ctz(slice);
-        f64x4 acc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = f64x4{0., 0., 0., 0.};
-        for (int c0 = k0; c0 < k1; c0 += slice) {
-            __syncthreads();           // rows[] written / previous chunk consumed
-#pragma unroll 4
-            for (int idx = threadIdx.x; idx < R16 * 16 * slice; idx += 256) {
-                const int rho = idx >> sh, px = idx & (slice - 1);
-                const double* rp = rows[rho];
-                ys[rho * ld + px] = (rp && c0 + px < k1) ? rp[c0 + px] : 0.0;
-            }
-            for (int px = threadIdx.x; px < slice; px += 256) qs[px] = c0 + px < k1 ? Qk[c0 + px] : 0.0;
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int t = wv + 4 * q;
-                if (t >= R16 * R16) break;
-                const int rb = t / R16, cb = t - rb * R16;
-                if (cb < rb) continue;  // symmetric: upper tiles only
-                const double* pa = ys + (rb * 16 + r) * ld;
-                const double* pb = ys + (cb * 16 + r) * ld;
-                for (int kk = 0; kk < slice; kk += 16) {
-                    const int px = kk + 4 * g;  // this lane's 4 consecutive pixels
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[px + s] * qs[px + s],
-                                                                      pb[px + s], acc[q], 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int t = wv + 4 * q;
-            if (t >= R16 * R16) break;
-            const int rb = t / R16, cb = t - rb * R16;
-            if (cb >= rb) scatter(rb, cb, acc[q]);
-        }
-        return;
-    }
-    // more than 64 rows (over ten edges leaving one frame): panels straight from global memory
-    for (int t = wv; t < R16 * R16; t += 4) {
+    for (int t = wv; t < R16 * R16; t += kSchurWaves) {
         const int rb = t / R16, cb = t - rb * R16;
         if (cb < rb) continue;
         f64x4 acc = {0., 0., 0., 0.};
@@ -627,7 +737,26 @@ __global__ __launch_bounds__(256) void dba_schur_kernel(int HW, int P, int slice
             for (int s = 0; s < 4; ++s)
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
         }
-        scatter(rb, cb, acc);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+            schur_add(W, n0, nrows, n6, rb * 16 + g + 4 * reg, cb * 16 + r, rb != cb, acc[reg]);
+    }
+}
+
+__global__ __launch_bounds__(kSchurThreads) void dba_schur_kernel(int HW, int P, int pxw, DbaWs W) {
+    __shared__ double red[10 * 256];
+    const int k = blockIdx.y;
+    if (W.status[2]) return;
+    const int n0 = W.ent_start[k], n1 = W.ent_start[k + 1];
+    const int nent = n1 - n0;
+    if (nent == 0) return;
+    const int nrows = 6 * nent + 1;
+    switch ((nrows + 15) / 16) {
+        case 1: schur_rows_body<1>(HW, P, pxw, k, n0, nrows, W, red); break;
+        case 2: schur_rows_body<2>(HW, P, pxw, k, n0, nrows, W, red); break;
+        case 3: schur_rows_body<3>(HW, P, pxw, k, n0, nrows, W, red); break;
+        case 4: schur_rows_body<4>(HW, P, pxw, k, n0, nrows, W, red); break;
+        default: schur_wide_body(HW, P, pxw, k, n0, nrows, W); break;
     }
 }
 
@@ -690,10 +819,12 @@ __global__ __launch_bounds__(1024) void dba_solve_kernel(int n, double lm, doubl
     }
 }
 
-// The same solve for n <= 64 on ONE wave, lane i owning row i: the 1024-lane version spends
-// its time in five workgroup barriers per column, which for the 6P = 48..78 unknowns of a real
-// window is nearly all of it.  Same operation order, hence the same bits.  Rows are padded to
-// an odd number of doubles so that the lanes' row accesses spread over the LDS banks.
+// The same solve for n <= 64 with lane i owning row i: the 1024-lane version spends its time
+// in five workgroup barriers per column, which for the 6P = 48..78 unknowns of a real window is
+// nearly all of it.  The factorisation runs in block columns of six, so the sums are grouped
+// differently from the column-by-column version (results agree to rounding, not bit for bit).
+// Rows are padded to an odd number of doubles so that the lanes' row accesses spread over the
+// LDS banks.
 __device__ __forceinline__ double lane_bcast(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
@@ -939,16 +1070,8 @@ static int stage_schur(const DbaDims& d, const DbaWs& W, hipStream_t s) {
     const int P = d.t1 - d.t0, HW = d.ht * d.wd;
     ProfScope prof(PROF_DBA_SCHUR, s);
     if (d.M > 0 && P > 0) {
-        const int span = schur_span(HW, d.M);
-        dim3 grid(cdiv(HW, span), d.M);
-        static bool lds_set = false;
-        if (!lds_set) {
-            VINGS_CHECK_HIP(hipFuncSetAttribute((const void*)dba_schur_kernel,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                (int)kSchurLds));
-            lds_set = true;
-        }
-        dba_schur_kernel<<<grid, 256, kSchurLds, s>>>(HW, P, kSchurSlice, span, W);
+        const SchurGrid sg = schur_grid(HW, d.M);
+        dba_schur_kernel<<<dim3(sg.gx, d.M), kSchurThreads, 0, s>>>(HW, P, sg.pxw, W);
         VINGS_LAUNCH_CHECK();
     }
     return VINGS_OK;
