@@ -45,6 +45,12 @@ CASES = [
     # the grid bench.py times (1080p / 8): the Schur kernel keeps its accumulators over
     # 2048-pixel spans here, which the smaller grids above do not reach
     dict(n_frames=9, ht=135, wd=240, n_edges=48),
+    # every ordered pair of 14 frames: 13 edges leave each frame, a depth variable couples 13
+    # poses = 79 rows, past the 64 the Schur kernel keeps in registers (its wide path)
+    dict(n_frames=14, ht=10, wd=13, n_edges=182, seed=21),
+    # every ordered pair of 36 frames: more edges per frame than the linearisation caches in
+    # LDS (32), and 210 unknowns, past what the solve keeps in LDS (128)
+    dict(n_frames=36, ht=6, wd=9, n_edges=1260, seed=22),
 ]
 
 

@@ -557,7 +557,15 @@ constexpr int kSchurThreads = 64 * kSchurWaves;
 // 16-pixel steps -- every further workgroup costs one more round of atomics on S.
 struct SchurGrid { int pxw, gx; };
 static SchurGrid schur_grid(int HW, int M) {
-    static const int target = [] { const char* e = getenv("VINGS_SCHUR_WGS"); return e ? atoi(e) : 256; }();
+    // VINGS_SCHUR_WGS overrides the workgroup target (the CU count of the current device)
+    static const int target = [] {
+        if (const char* e = getenv("VINGS_SCHUR_WGS")) return atoi(e);
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        return cus;
+    }();
     int gx = target / (M > 0 ? M : 1);
     gx = min(gx, HW / (32 * kSchurWaves));
     if (gx < 1) gx = 1;
