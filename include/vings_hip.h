@@ -643,10 +643,10 @@ typedef struct vings_dba_layout {
     size_t off_E;         /* double [(P+E),6,HW] coupling rows: P per-pose rows, then per edge */
     size_t off_Q;         /* double [M,HW] inverse of the depth block                     */
     size_t off_w;         /* double [M,HW] depth residual                                */
-    size_t off_H;         /* double [6P,6P] undamped pose block                          */
-    size_t off_v;         /* double [6P]                                                 */
-    size_t off_S;         /* double [6P,6P] Schur complement E Q E^T                     */
-    size_t off_u;         /* double [6P]    E Q w                                        */
+    size_t off_H;         /* double [8][6P,6P] undamped pose block as 8 partial sums, lower triangle only */
+    size_t off_v;         /* double [8][6P] as 8 partial sums                            */
+    size_t off_S;         /* double [8][6P,6P] Schur complement E Q E^T, like H          */
+    size_t off_u;         /* double [8][6P] E Q w as 8 partial sums                      */
     size_t off_dx;        /* double [6P]    pose update                                  */
     size_t off_chol;      /* double [6P,6P] factorisation scratch                        */
     size_t off_kx;        /* int32  [M] frame of each depth variable                     */

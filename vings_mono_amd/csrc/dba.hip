@@ -36,6 +36,12 @@
 namespace vings {
 
 constexpr double kMinDepth = 0.2;
+// H, v, S and u are accumulated as kHCopies partial sums, a workgroup of the linearisation or
+// of the Schur kernel adding to copy (its index mod kHCopies): every element is the target of
+// one float64 atomic per workgroup and edge (or depth variable), a few hundred per element and
+// launch, and atomics on one address are served one after the other (linearisation 85 -> 65 us
+// when the copies came in).  The readers add the copies up (h_sum, v_sum, s_sum, u_sum).
+constexpr int kHCopies = 8;
 constexpr double kSensorAlpha = 0.05;
 constexpr int kMaxFrames = 4096;
 
@@ -43,10 +49,10 @@ struct DbaWs {  // typed view of the caller's workspace
     double* E;       // [(P+E),6,HW]
     double* Q;       // [M,HW]
     double* w;       // [M,HW]
-    double* H;       // [6P,6P]
-    double* v;       // [6P]
-    double* S;       // [6P,6P]
-    double* u;       // [6P]
+    double* H;       // [kHCopies][6P,6P] partial sums; lower triangle (row >= column), the rest stays zero
+    double* v;       // [kHCopies][6P] partial sums
+    double* S;       // [kHCopies][6P,6P] partial sums of the lower triangle, like H
+    double* u;       // [kHCopies][6P] partial sums
     double* dx;      // [6P]
     double* chol;    // [6P,6P]
     int* kx;         // [M]
@@ -71,10 +77,10 @@ static void layout(int ht, int wd, int E, int P, int M, vings_dba_layout* L) {
     L->off_E = take(sizeof(double) * (size_t)(P + E) * 6 * HW);
     L->off_Q = take(sizeof(double) * (size_t)M * HW);
     L->off_w = take(sizeof(double) * (size_t)M * HW);
-    L->off_H = take(sizeof(double) * n * n);
-    L->off_v = take(sizeof(double) * n);
-    L->off_S = take(sizeof(double) * n * n);
-    L->off_u = take(sizeof(double) * n);
+    L->off_H = take(sizeof(double) * n * n * kHCopies);
+    L->off_v = take(sizeof(double) * n * kHCopies);
+    L->off_S = take(sizeof(double) * n * n * kHCopies);
+    L->off_u = take(sizeof(double) * n * kHCopies);
     L->off_dx = take(sizeof(double) * n);
     L->off_chol = take(sizeof(double) * n * n);
     L->off_kx = take(sizeof(int) * (size_t)(M + 1));
@@ -101,6 +107,31 @@ static DbaWs carve(void* ws, const vings_dba_layout& L) {
     W.ent_start = (int*)(p + L.off_ent_start); W.ent_row = (int*)(p + L.off_ent_row);
     W.ent_pose = (int*)(p + L.off_ent_pose); W.status = (int*)(p + L.off_status);
     return W;
+}
+
+__device__ __forceinline__ double h_sum(const DbaWs& W, int n, int lo) {
+    double a = 0.0;
+#pragma unroll
+    for (int c = 0; c < kHCopies; ++c) a += W.H[(size_t)c * n * n + lo];
+    return a;
+}
+__device__ __forceinline__ double s_sum(const DbaWs& W, int n, int lo) {
+    double a = 0.0;
+#pragma unroll
+    for (int c = 0; c < kHCopies; ++c) a += W.S[(size_t)c * n * n + lo];
+    return a;
+}
+__device__ __forceinline__ double u_sum(const DbaWs& W, int n, int i) {
+    double a = 0.0;
+#pragma unroll
+    for (int c = 0; c < kHCopies; ++c) a += W.u[(size_t)c * n + i];
+    return a;
+}
+__device__ __forceinline__ double v_sum(const DbaWs& W, int n, int i) {
+    double a = 0.0;
+#pragma unroll
+    for (int c = 0; c < kHCopies; ++c) a += W.v[(size_t)c * n + i];
+    return a;
 }
 
 // ---------------------------------------------------------------------------
@@ -342,7 +373,6 @@ __global__ __launch_bounds__(256) void dba_linearize_kernel(
     DbaWs W) {
     constexpr int kTileLd = 17;
     __shared__ double tile[4][64 * kTileLd];   // per wave: its pixels' 13-vectors (+ 3 zero rows)
-    __shared__ double wts[4][64];
     __shared__ double Cs[2][4][13 * 13];       // the waves' products, double-buffered over the edges
     const int k = blockIdx.y;
     const int HW = ht * wd;
@@ -364,6 +394,8 @@ __global__ __launch_bounds__(256) void dba_linearize_kernel(
     const int ca = threadIdx.x / 13, cb = threadIdx.x - ca * 13;
     const bool own_block = threadIdx.x < 13 * 13 && ca < 6 && (cb < 6 || cb == 12);
     const int n6 = 6 * P, ib = (i - t0) * 6;
+    double* const Hmine = W.H + (size_t)(blockIdx.x % kHCopies) * n6 * n6;
+    double* const vmine = W.v + (size_t)(blockIdx.x % kHCopies) * n6;
     double carry = 0.0;
     int buf = 0;
     // rows 13..15 of the MFMA operands stay zero for the whole kernel
@@ -397,8 +429,12 @@ __global__ __launch_bounds__(256) void dba_linearize_kernel(
         tw[0] = target[o]; tw[1] = target[o + HW]; tw[2] = weight[o]; tw[3] = weight[o + HW];
     };
     float tw_next[4];
-    fetch(e0, tw_next);
-    for (int idx = e0; idx < e1; ++idx) {
+    const int ne = e1 - e0;
+    const int rot = ne > 0 ? (int)(blockIdx.x % (unsigned)ne) : 0;
+    auto edge_at = [&](int t) { int q = t + rot; if (q >= ne) q -= ne; return e0 + q; };
+    fetch(ne > 0 ? edge_at(0) : e1, tw_next);
+    for (int t = 0; t < ne; ++t) {
+        const int idx = edge_at(t);
         const bool cached = idx - e0 < kEdgeCache;
         const int e = cached ? s_e[idx - e0] : W.kedges[idx];
         const int j = cached ? s_j[idx - e0] : W.jp[e];
@@ -413,7 +449,7 @@ __global__ __launch_bounds__(256) void dba_linearize_kernel(
             G = relative_pose(poses, i, j);
         }
         float tw[4] = {tw_next[0], tw_next[1], tw_next[2], tw_next[3]};
-        fetch(idx + 1, tw_next);
+        fetch(t + 1 < ne ? edge_at(t + 1) : e1, tw_next);
         double X1[3];
         qrot(G.q, X0, X1);
         X1[0] += G.t[0] * d; X1[1] += G.t[1] * d; X1[2] += G.t[2] * d;
@@ -467,9 +503,9 @@ __global__ __launch_bounds__(256) void dba_linearize_kernel(
         // J^T W J of this edge on the matrix cores.  Per residual row c the lane's pixel has the
         // 13-vector a = (Ji[c][0..5], Jj[c][0..5], r[c]); the 13 x 13 matrix sum_pixels wt a a^T
         // holds Hii, Hij, Hjj, vi and vj.  v_mfma_f64_16x16x4_f64 takes four pixels at a time:
-        // lane l supplies A[row l&15][pixel l>>4] and B = wt * the same element, so every lane
-        // reads ONE value per instruction from a per-wave LDS tile that the lanes filled with
-        // their own vectors (pixel-major rows of 17 doubles: the 16 rows of an operand are
+        // lane l supplies A[row l&15][pixel l>>4] = sqrt(wt) * a and the same element as B, so
+        // every lane reads ONE value per instruction from a per-wave LDS tile that the lanes
+        // filled with their own vectors (pixel-major rows of 17 doubles: the 16 rows of an operand are
         // consecutive words, the four pixels of it 34 banks apart).  16 instructions per
         // residual row replace 90 products and the 90-value wave reduction that followed them.
         {
@@ -477,19 +513,20 @@ __global__ __launch_bounds__(256) void dba_linearize_kernel(
             f64x4 acc = {0., 0., 0., 0.};
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
+                // (the weight goes in as its square root on both sides: one operand, one LDS
+                // read per instruction, and no per-instruction multiply)
+                const double sw = sqrt(wt[c]);
                 double* mine = T + lane * kTileLd;
 #pragma unroll
-                for (int m = 0; m < 6; ++m) { mine[m] = Ji[c][m]; mine[6 + m] = Jj[c][m]; }
-                mine[12] = r[c];
-                wts[wv][lane] = wt[c];
+                for (int m = 0; m < 6; ++m) { mine[m] = sw * Ji[c][m]; mine[6 + m] = sw * Jj[c][m]; }
+                mine[12] = sw * r[c];
                 // same wave writes and reads: LDS operations of a wave complete in order
                 __builtin_amdgcn_wave_barrier();
                 const double* src = T + (lane >> 4) * kTileLd + (lane & 15);
-                const double* wsrc = wts[wv] + (lane >> 4);
 #pragma unroll
                 for (int m = 0; m < 16; ++m) {
                     const double a = src[4 * m * kTileLd];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a * wsrc[4 * m], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -516,16 +553,17 @@ __global__ __launch_bounds__(256) void dba_linearize_kernel(
                 const bool a_i = ca < 6, b_i = cb < 6;
                 if ((a_i ? i_free : j_free) && (cb == 12 || (b_i ? i_free : j_free))) {
                     const int ra = a_i ? ib + ca : jb + ca - 6;
-                    if (cb == 12) atomicAdd(&W.v[ra], s);
-                    else atomicAdd(&W.H[(size_t)ra * n6 + (b_i ? ib + cb : jb + cb - 6)], s);
+                    const int rb = b_i ? ib + cb : jb + cb - 6;
+                    if (cb == 12) atomicAdd(&vmine[ra], s);
+                    else if (ra >= rb) atomicAdd(&Hmine[(size_t)ra * n6 + rb], s);   // lower triangle only
                 }
             }
         }
         buf ^= 1;
     }
     if (own_block && i_free && carry != 0.0) {
-        if (cb == 12) atomicAdd(&W.v[ib + ca], carry);
-        else atomicAdd(&W.H[(size_t)(ib + ca) * n6 + ib + cb], carry);
+        if (cb == 12) atomicAdd(&vmine[ib + ca], carry);
+        else if (ca >= cb) atomicAdd(&Hmine[(size_t)(ib + ca) * n6 + ib + cb], carry);
     }
     if (motion_only || !act) return;
     if (i_free) {
@@ -578,16 +616,21 @@ static SchurGrid schur_grid(int HW, int M) {
 // a tile above the diagonal also feeds its mirror image
 __device__ __forceinline__ void schur_add(const DbaWs& W, int n0, int nrows, int n6, int ra, int rc,
                                           bool mirror, double val) {
+    double* const S = W.S + (size_t)(blockIdx.x % kHCopies) * n6 * n6;
+    double* const u = W.u + (size_t)(blockIdx.x % kHCopies) * n6;
     if (ra >= nrows - 1 || rc >= nrows || val == 0.0) return;
     const int ea = ra / 6, ca = ra - ea * 6;
     const int ia = W.ent_pose[n0 + ea] * 6 + ca;
     if (rc == nrows - 1) {
-        atomicAdd(&W.u[ia], val);
+        atomicAdd(&u[ia], val);
     } else {
         const int eb = rc / 6, cc = rc - eb * 6;
         const int ibx = W.ent_pose[n0 + eb] * 6 + cc;
-        atomicAdd(&W.S[(size_t)ia * n6 + ibx], val);
-        if (mirror) atomicAdd(&W.S[(size_t)ibx * n6 + ia], val);
+        // lower triangle only: of the ordered pair and (from a tile above the diagonal) its
+        // mirror image, whichever lands on or below the diagonal; two rows of the same pose and
+        // component (a frame that is its own target) put both on the diagonal element
+        if (ia >= ibx) atomicAdd(&S[(size_t)ia * n6 + ibx], val);
+        if (mirror && ibx >= ia) atomicAdd(&S[(size_t)ibx * n6 + ia], val);
     }
 }
 
@@ -780,9 +823,10 @@ __global__ __launch_bounds__(1024) void dba_solve_kernel(int n, double lm, doubl
     if (tid == 0) fail = 0;
     for (int idx = tid; idx < n * n; idx += 1024) {
         const int i = idx / n, j = idx - i * n;
-        double a = W.H[idx];
+        const int lo = max(i, j) * n + min(i, j);      // H and S hold their lower triangles
+        double a = h_sum(W, n, lo);
         if (i == j) a += ep + lm * a;
-        if (use_schur) a -= W.S[idx];
+        if (use_schur) a -= s_sum(W, n, lo);
         A[idx] = a;
     }
     __syncthreads();
@@ -809,7 +853,7 @@ __global__ __launch_bounds__(1024) void dba_solve_kernel(int n, double lm, doubl
     }
     // forward / backward substitution with the lower factor (serial over rows)
     double* y = W.dx;
-    for (int i = tid; i < n; i += 1024) y[i] = W.v[i] - (use_schur ? W.u[i] : 0.0);
+    for (int i = tid; i < n; i += 1024) y[i] = v_sum(W, n, i) - (use_schur ? u_sum(W, n, i) : 0.0);
     __syncthreads();
     for (int j = 0; j < n; ++j) {
         if (tid == 0) y[j] /= A[j * n + j];
@@ -851,12 +895,39 @@ __global__ __launch_bounds__(256) void dba_solve_wave_kernel(int n, double lm, d
     if (i == 0) fail_s = 0;
     // four waves fetch the matrix (one wave alone would queue 36 dependent-latency rounds of
     // global loads)
-    for (int idx = i; idx < n * n; idx += 256) {
-        const int r = idx / n, c = idx - r * n;
-        double a = W.H[idx];
-        if (r == c) a += ep + lm * a;
-        if (use_schur) a -= W.S[idx];
-        A[r * ld + c] = a;
+    // H and S hold their lower triangles as kHCopies partial sums each: an element costs 16
+    // loads, so a lane fetches three elements (48 loads in flight) before it adds anything up,
+    // and writes each into both halves of A.
+    const int nlow = n * (n + 1) / 2;
+    for (int base = i; base < nlow; base += 3 * 256) {
+        double hv[3][kHCopies], sv[3][kHCopies];
+        int rr[3], cc[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int idx = min(base + 256 * q, nlow - 1);
+            // row of triangular index idx: largest r with r (r + 1) / 2 <= idx
+            int r = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+            r += ((r + 1) * (r + 2) / 2 <= idx) ? 1 : 0;
+            r -= (r * (r + 1) / 2 > idx) ? 1 : 0;
+            rr[q] = r; cc[q] = idx - r * (r + 1) / 2;
+            const int lo = r * n + cc[q];
+#pragma unroll
+            for (int c = 0; c < kHCopies; ++c) {
+                hv[q][c] = W.H[(size_t)c * n * n + lo];
+                sv[q][c] = use_schur ? W.S[(size_t)c * n * n + lo] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (base + 256 * q >= nlow) break;
+            double a = 0.0, sc = 0.0;
+#pragma unroll
+            for (int c = 0; c < kHCopies; ++c) { a += hv[q][c]; sc += sv[q][c]; }
+            if (rr[q] == cc[q]) a += ep + lm * a;
+            a -= sc;
+            A[rr[q] * ld + cc[q]] = a;
+            A[cc[q] * ld + rr[q]] = a;
+        }
     }
     __syncthreads();
     // Right-looking factorisation in block columns of six (n = 6 P: one pose per block), two
@@ -939,7 +1010,7 @@ __global__ __launch_bounds__(256) void dba_solve_wave_kernel(int n, double lm, d
     // element travels by v_readlane and is multiplied by the reciprocal pivot, so a step is
     // a few dependent instructions instead of two LDS round trips, a division and two barriers.
     const bool live = i < n;
-    double yi = live ? W.v[i] - (use_schur ? W.u[i] : 0.0) : 0.0;
+    double yi = live ? v_sum(W, n, i) - (use_schur ? u_sum(W, n, i) : 0.0) : 0.0;
     const double* rowi = A + (live ? i : 0) * ld;
     for (int j = 0; j < n; ++j) {                      // L y = b
         const double yj = lane_bcast(yi, j) * lane_bcast(rd, j);
@@ -1010,8 +1081,12 @@ __global__ void dba_pose_retract_kernel(float* __restrict__ poses, int t0, int P
 __global__ void dba_reduced_kernel(int n, DbaWs W, double* __restrict__ Hout,
                                    double* __restrict__ vout) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < n * n) Hout[idx] = W.H[idx] - W.S[idx];
-    if (idx < n) vout[idx] = W.v[idx] - W.u[idx];
+    if (idx < n * n) {
+        const int r = idx / n, c = idx - r * n;
+        const int lo = max(r, c) * n + min(r, c);      // H and S hold their lower triangles
+        Hout[idx] = h_sum(W, n, lo) - s_sum(W, n, lo);
+    }
+    if (idx < n) vout[idx] = v_sum(W, n, idx) - u_sum(W, n, idx);
 }
 
 // float32 copies of Q and E for the depth-covariance consumer; rows of E that
@@ -1059,7 +1134,7 @@ static int stage_linearize(const float* poses, const float* disps, const float* 
     ProfScope prof(PROF_DBA_JAC, s);
     // H, v, S and u lie next to each other in the workspace: one fill command clears the
     // four accumulators of this iteration (the Schur stage always follows this one)
-    VINGS_CHECK_HIP(hipMemsetAsync(W.H, 0, (size_t)((char*)(W.u + n) - (char*)W.H), s));
+    VINGS_CHECK_HIP(hipMemsetAsync(W.H, 0, (size_t)((char*)(W.u + n * kHCopies) - (char*)W.H), s));
     if (build_index) {
         dba_index_kernel<<<1, 256, 0, s>>>(ii, jj, d.B, d.E, d.M, d.t0, d.t1, W);
         VINGS_LAUNCH_CHECK();
