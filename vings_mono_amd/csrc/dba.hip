@@ -877,6 +877,26 @@ __global__ __launch_bounds__(1024) void dba_solve_kernel(int n, double lm, doubl
 // differently from the column-by-column version (results agree to rounding, not bit for bit).
 // Rows are padded to an odd number of doubles so that the lanes' row accesses spread over the
 // LDS banks.
+// 1 / sqrt(d) for d > 0 from v_rsq_f64 (good to about 2^-23) and two Newton steps, a chain
+// of 8 dependent instructions; sqrt() followed by a division is about 30, and the
+// factorisation below is one such chain per column with little else beside it.
+__device__ __forceinline__ double rsqrt_nr(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
+}
+
+// row r of element idx of a lower triangle stored row by row: the largest r with
+// r (r + 1) / 2 <= idx (idx < 2^22: the float estimate is off by at most one)
+__device__ __forceinline__ int tri_row(int idx) {
+    int r = (int)((__builtin_sqrtf(8.f * (float)idx + 1.f) - 1.f) * 0.5f);
+    r += ((r + 1) * (r + 2) / 2 <= idx) ? 1 : 0;
+    r -= (r * (r + 1) / 2 > idx) ? 1 : 0;
+    return r;
+}
+
 __device__ __forceinline__ double lane_bcast(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
@@ -905,10 +925,7 @@ __global__ __launch_bounds__(256) void dba_solve_wave_kernel(int n, double lm, d
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int idx = min(base + 256 * q, nlow - 1);
-            // row of triangular index idx: largest r with r (r + 1) / 2 <= idx
-            int r = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-            r += ((r + 1) * (r + 2) / 2 <= idx) ? 1 : 0;
-            r -= (r * (r + 1) / 2 > idx) ? 1 : 0;
+            const int r = tri_row(idx);
             rr[q] = r; cc[q] = idx - r * (r + 1) / 2;
             const int lo = r * n + cc[q];
 #pragma unroll
@@ -946,7 +963,7 @@ __global__ __launch_bounds__(256) void dba_solve_wave_kernel(int n, double lm, d
 #pragma unroll
                 for (int k = 0; k < c; ++k) d -= L[c][k] * L[c][k];
                 bad |= !(d > 0.0);
-                inv[c] = 1.0 / sqrt(d);
+                inv[c] = rsqrt_nr(d);          // (garbage for d <= 0: the block is flagged bad)
                 L[c][c] = d * inv[c];
 #pragma unroll
                 for (int r = c + 1; r < 6; ++r) {
@@ -986,9 +1003,8 @@ __global__ __launch_bounds__(256) void dba_solve_wave_kernel(int n, double lm, d
         __syncthreads();
         if (fail_s) break;
         const int m0 = j0 + 6, m = n - m0;
-        for (int idx = i; idx < m * m; idx += 256) {
-            const int r = idx / m, c = idx - r * m;
-            if (c > r) continue;
+        for (int idx = i; idx < m * (m + 1) / 2; idx += 256) {   // the lower triangle only
+            const int r = tri_row(idx), c = idx - r * (r + 1) / 2;
             const double* pr = panel[m0 + r];
             const double* pc = panel[m0 + c];
             double acc = 0.0;
