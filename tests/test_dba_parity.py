@@ -51,6 +51,9 @@ CASES = [
     # every ordered pair of 36 frames: more edges per frame than the linearisation caches in
     # LDS (32), and 210 unknowns, past what the solve keeps in LDS (128)
     dict(n_frames=36, ht=6, wd=9, n_edges=1260, seed=22),
+    # fewer pixels than one 16-pixel step of the Schur kernel, two frames, one free pose
+    dict(n_frames=2, ht=3, wd=4, n_edges=2, seed=23),
+    dict(n_frames=3, ht=1, wd=17, n_edges=6, seed=24),
 ]
 
 
