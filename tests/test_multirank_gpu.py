@@ -1,4 +1,4 @@
-"""Two and four ranks of the sharded mapping loop on the GPU: replicas must stay bit-identical
+"""Two, four and eight ranks of the sharded mapping loop on the GPU: replicas must stay bit-identical
 after every exchanged step, the fused C-ABI view step must agree with the autograd-driven
 formulation of the same step, and its compact exchange (touched rows only, in chunks) with
 its planar one.  The ranks share the test box's single GPU and exchange over gloo; on a
@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_multi_rank_view_steps(tmp_path, world):
     out = str(tmp_path / "state")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
