@@ -1,5 +1,5 @@
 #!/bin/bash
-# first GPU pass of round 3: new multi-rank tests, self-launching bench, the two side workloads
+# multi-rank tests, the self-launching bench and the two side workloads in one GPU call
 set -e
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r3

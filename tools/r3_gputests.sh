@@ -1,5 +1,5 @@
 #!/bin/bash
-# the whole GPU suite the way the round's end runs it
+# the whole GPU suite in one process, slowest tests listed
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r3
 timeout -k 10 1100 python -u -m pytest tests -x -q -m gpu --timeout 600 --timeout-method thread --durations=15 > gpurun_out/r3/gputests.log 2>&1

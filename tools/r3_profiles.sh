@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 evidence: kernel statistics of the bench command, HBM and SQ counter passes of the
+# Evidence behind the measured numbers: kernel statistics of the bench command, HBM and SQ counter passes of the
 # view step (default map and half of it stable), and counter passes of the dense-BA kernels.
 # Every GPU step has its own time limit; the chain stops at the first failure.
 set -o pipefail
