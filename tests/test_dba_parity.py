@@ -420,3 +420,39 @@ def test_altcorr_full_grid_properties():
     inside = ((x0 >= 0) & (x0 + 2 * r + 1 < W - 5) & (y0 >= 0) & (y0 + 2 * r + 1 < H - 3))[:, :, None]
     assert float(inside.float().mean()) > 0.7
     assert float(((e - a).abs() * inside).max()) <= 2e-5 * float(a.abs().max())
+
+
+def test_schur_grid_does_not_change_the_update(tmp_path):
+    """The Schur kernel's launch shape (workgroups per depth variable, pixels per wave) is a
+    tuning choice: far fewer and far more workgroups than the default must give the same pose
+    update up to the order of the float64 additions.  The target is read once per process, so
+    each setting runs in a process of its own."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from vings_mono_amd import dba, synth\n"
+        "p = synth.make_dba_problem(n_frames=9, ht=67, wd=120, n_edges=48, seed=11)\n"
+        "f = lambda a: torch.from_numpy(np.asarray(a)).float().cuda().contiguous()\n"
+        "ii, jj = torch.from_numpy(p['ii']).cuda(), torch.from_numpy(p['jj']).cuda()\n"
+        "poses, disps = f(p['poses']), f(p['disps'])\n"
+        "dba.ba(poses, disps, f(p['intr']), f(p['disps_sens']), f(p['target']), f(p['weight']), f(p['eta']),\n"
+        "       ii, jj, p['t0'], p['t1'], 1, 1e-4, 0.1, False)\n"
+        "dx, st = dba.last_update()\n"
+        "assert not st['cholesky_failed']\n"
+        "np.save(sys.argv[1], dx.numpy())\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for wgs in ("9", "", "4096"):
+        out = str(tmp_path / f"dx_{wgs or 'default'}.npy")
+        env = dict(os.environ)
+        env.pop("VINGS_SCHUR_WGS", None)
+        if wgs:
+            env["VINGS_SCHUR_WGS"] = wgs
+        res = subprocess.run([sys.executable, "-c", code, out], env=env, capture_output=True, text=True,
+                             timeout=300)
+        assert res.returncode == 0, res.stderr[-3000:]
+        outs.append(np.load(out))
+    for other in (outs[0], outs[2]):
+        assert rel(other, outs[1]) < 1e-10, rel(other, outs[1])
